@@ -1,0 +1,178 @@
+"""Pin the CPU oracle (oracle/) against the golden fixtures captured from the
+reference (tests/golden/make_golden.py) and against oracle/_ref (the reference's
+sampling.cpp compiled in place).  CPU only."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_glibc_rand_known_answers(oracle):
+    # srand(2020) -> rand() = 881877917, 848339315, 706777409
+    oracle.srand(2020)
+    assert [oracle.rand() for _ in range(3)] == [881877917, 848339315, 706777409]
+    meta = json.load(open(os.path.join(GOLDEN, "gowalla", "golden_samplers.json")))
+    oracle.srand(2020)
+    assert [oracle.randint(1000) for _ in range(5)] == meta["rand_mod_1000"]
+
+
+def test_glibc_rand_matches_libc(oracle):
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 1, 2020, 123456789, 0xFFFFFFFF):
+        libc.srand(ctypes.c_uint(seed))
+        oracle.srand(seed)
+        assert [libc.rand() for _ in range(2000)] == [oracle.rand() for _ in range(2000)]
+
+
+def test_numpy_legacy_stream(oracle):
+    for seed in (0, 2020, 99):
+        np.random.seed(seed)
+        oracle.np_seed(seed)
+        a = np.random.randint(0, 29858, 5000)
+        assert np.array_equal(a, oracle.np_randint(29858, 5000))
+        idx = np.arange(10007)
+        np.random.shuffle(idx)
+        assert np.array_equal(idx, oracle.np_shuffle_arange(10007))
+        assert np.random.randint(0, 1 << 31) == oracle.np_randint(1 << 31, 1)[0]
+
+
+def test_sampler_cpp_tiny(oracle, tiny):
+    ip, ix, _ = oracle.user_item_csr(tiny.n_users, tiny.m_items, tiny.train_user, tiny.train_item)
+    oracle.srand(2020)
+    for e in (1, 2):
+        S = oracle.sample_negative(tiny.n_users, tiny.m_items, len(tiny.train_user), ip, ix, 1)
+        assert S.dtype == np.int32 and np.array_equal(S, tiny.z[f"S_epoch{e}"])
+
+
+def test_sampler_python_tiny(oracle, tiny):
+    z = np.load(os.path.join(tiny.dir, "golden_python_sampler.npz"))
+    ip, ix, _ = oracle.user_item_csr(tiny.n_users, tiny.m_items, tiny.train_user, tiny.train_item)
+    oracle.np_seed(2020)
+    S1 = oracle.sample_python(tiny.n_users, tiny.m_items, len(tiny.train_user), ip, ix)
+    perm = oracle.np_shuffle_arange(len(S1))
+    S2 = oracle.sample_python(tiny.n_users, tiny.m_items, len(tiny.train_user), ip, ix)
+    assert np.array_equal(S1, z["S_python_epoch1"])
+    assert np.array_equal(perm, z["perm_after_epoch1"])
+    assert np.array_equal(S2, z["S_python_epoch2"])
+
+
+def test_sampler_python_lastfm(oracle, lastfm):
+    ip, ix, _ = oracle.user_item_csr(lastfm.n_users, lastfm.m_items, lastfm.train_user, lastfm.train_item)
+    oracle.np_seed(2020)
+    S = oracle.sample_python(lastfm.n_users, lastfm.m_items, len(lastfm.train_user), ip, ix)
+    assert sha(S) == lastfm.meta["S_epoch1_sha256"] and len(S) == 41830
+    assert S[:2].tolist() == [[864, 1336, 1402], [392, 913, 4405]]
+    perm = oracle.np_shuffle_arange(len(S))
+    assert np.array_equal(S[perm, 0], lastfm.z["shuf_users_epoch1"])
+
+
+def test_sampler_vs_compiled_reference(oracle, tiny):
+    """oracle/_ref/sampling*.so is the reference's own sampling.cpp built in place."""
+    ref_dir = os.path.join(REPO, "oracle", "_ref")
+    if not any(f.startswith("sampling") and f.endswith(".so") for f in os.listdir(ref_dir) if True):
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, ref_dir)
+    import sampling as ref
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_users, m_items = 300, 500
+    rows = [np.sort(rng.choice(m_items, size=int(rng.integers(1, 60)), replace=False)).astype(np.int32)
+            for _ in range(n_users)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows)
+    train_num = int(indptr[-1])
+    for seed in (2020, 7):
+        ref.seed(seed)
+        oracle.srand(seed)
+        for _ in range(2):
+            a = ref.sample_negative(n_users, m_items, train_num, rows, 1)
+            b = oracle.sample_negative(n_users, m_items, train_num, indptr, indices, 1)
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        us = rng.integers(0, n_users, 77).astype(np.int32)
+        a = ref.sample_negative_ByUser(us.tolist(), m_items, rows, 3)
+        b = oracle.sample_negative_by_user(us, m_items, indptr, indices, 3)
+        assert np.array_equal(a, b)
+        assert ref.randint(1000) == oracle.randint(1000)
+
+
+def test_norm_adj_bit_exact(oracle, tiny, lastfm):
+    for g in (tiny, lastfm):
+        ip, ix, vv = oracle.user_item_csr(g.n_users, g.m_items, g.train_user, g.train_item)
+        indptr, indices, data, _ = oracle.build_norm_adj(g.n_users, g.m_items, ip, ix, vv)
+        assert np.array_equal(indptr, g.z["adj_indptr"])
+        assert np.array_equal(indices, g.z["adj_indices"])
+        assert np.array_equal(data.view(np.uint32), g.z["adj_data"].view(np.uint32))
+
+
+def test_propagate(oracle, tiny, lastfm):
+    for g in (tiny, lastfm):
+        out = oracle.propagate(g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"], g.e0(), g.K)
+        ref = np.concatenate([g.z["computer_users"], g.z["computer_items"]], 0)
+        got = np.concatenate([out[:g.n_users][::g.stride], out[g.n_users:][::g.stride]], 0)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-7)
+
+
+def test_bpr_loss_and_grads(oracle, tiny, lastfm):
+    for g in (tiny, lastfm):
+        A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+        E = oracle.propagate(*A, g.e0(), g.K)
+        l, r, G = oracle.bpr(E, g.n_users, g.z["b_users"], g.z["b_pos"], g.z["b_neg"], g.meta["decay"])
+        assert abs(l - g.meta["b_loss"]) < 2e-6 and abs(r - g.meta["b_reg"]) < 2e-6
+        grad = oracle.propagate_bwd(*A, G, g.K)
+        np.testing.assert_allclose(grad[:g.n_users][::g.stride], g.z["b_grad_user"], rtol=2e-4, atol=2e-9)
+        np.testing.assert_allclose(grad[g.n_users:][::g.stride], g.z["b_grad_item"], rtol=2e-4, atol=2e-9)
+
+
+def _run_epoch(oracle, g, tr, users, pos, neg):
+    losses = []
+    for s in range(0, len(users), g.B):
+        losses.append(tr.stageOne(users[s:s + g.B], pos[s:s + g.B], neg[s:s + g.B]))
+    return np.asarray(losses)
+
+
+def test_train_epochs_tiny(oracle, tiny):
+    g = tiny
+    tr = oracle.Trainer(g.n_users, g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"], g.e0(), g.K,
+                        g.meta["decay"], g.meta["lr"])
+    for e in (1, 2):
+        losses = _run_epoch(oracle, g, tr, g.z[f"shuf_users_epoch{e}"], g.z[f"shuf_pos_epoch{e}"],
+                            g.z[f"shuf_neg_epoch{e}"])
+        np.testing.assert_allclose(losses, g.z[f"losses_epoch{e}"], rtol=0, atol=2e-6)
+        P = np.concatenate([g.z[f"P_user_epoch{e}"], g.z[f"P_item_epoch{e}"]], 0)
+        np.testing.assert_allclose(tr.e0, P, rtol=0, atol=5e-6)
+        if e == 1:
+            assert tr.step == g.meta["adam_step_epoch1"]
+            np.testing.assert_allclose(tr.m[:g.n_users], g.z["adam_m_user_epoch1"], rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(tr.v[g.n_users:], g.z["adam_v_item_epoch1"], rtol=1e-3, atol=1e-12)
+
+
+def test_train_epoch_lastfm_and_metrics(oracle, lastfm):
+    g = lastfm
+    ip, ix, _ = oracle.user_item_csr(g.n_users, g.m_items, g.train_user, g.train_item)
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    E = oracle.propagate(*A, g.e0(), g.K)
+    m0 = oracle.test(E, g.n_users, ip, ix, g.test_dict(), 20)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(m0[k] - g.meta["test_epoch0"][k][0]) < 1e-7, (k, m0[k])
+    # epoch 1 through the oracle's own python-mode sampler + shuffle
+    oracle.np_seed(2020)
+    S = oracle.sample_python(g.n_users, g.m_items, len(g.train_user), ip, ix)
+    perm = oracle.np_shuffle_arange(len(S))
+    S = S[perm]
+    tr = oracle.Trainer(g.n_users, *A, g.e0(), g.K, g.meta["decay"], g.meta["lr"])
+    losses = _run_epoch(oracle, g, tr, S[:, 0], S[:, 1], S[:, 2])
+    np.testing.assert_allclose(losses, g.z["losses_epoch1"], rtol=0, atol=3e-6)
+    assert abs(losses[0] - 0.68791) < 1e-5 and abs(losses[-1] - 0.68628) < 1e-5
+    E = oracle.propagate(*A, tr.e0, g.K)
+    m1 = oracle.test(E, g.n_users, ip, ix, g.test_dict(), 20)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(m1[k] - g.meta["test_epoch1"][k][0]) < 1e-4, (k, m1[k], g.meta["test_epoch1"][k])
