@@ -1,0 +1,126 @@
+"""ctypes binding of liblgcn_hip.so (include/lgcn_hip.h).
+
+There is NO fallback: if the library cannot be loaded the import of any compute
+entry point raises, loudly.  The CPU oracle under oracle/ is test infrastructure
+and is never reached from here."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+F32, BF16 = 0, 1
+MAX_LAYERS = 8
+
+_c_i32p = C.POINTER(C.c_int32)
+_c_i64p = C.POINTER(C.c_int64)
+_c_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class TrainConfig(C.Structure):
+    """Mirror of lgcn_train_config (include/lgcn_hip.h)."""
+    _fields_ = [
+        ("indptr", _vp), ("indices", _vp), ("vals", _vp),
+        ("N", C.c_int64), ("nnz", C.c_int64),
+        ("n_users", C.c_int32), ("d", C.c_int32), ("K", C.c_int32), ("act_dtype", C.c_int32),
+        ("E0", _vp), ("adam_m", _vp), ("adam_v", _vp),
+        ("act", _vp), ("G64", _vp), ("Gs", _vp), ("bitmap", _vp), ("terms", _vp), ("contrib", _vp),
+        ("err", _vp), ("max_batch", C.c_int32),
+        ("decay", C.c_float),
+        ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+        ("xcd_remap", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/lgcn_hip.h declares
+SIGNATURES = {
+    "lgcn_abi_version": (C.c_int, []),
+    "lgcn_last_error": (C.c_char_p, []),
+    "lgcn_device_available": (C.c_int, []),
+    "lgcn_sampling_seed": (None, [C.c_uint]),
+    "lgcn_sampling_randint": (C.c_int, [C.c_int]),
+    "lgcn_sample_negative": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_int, _vp]),
+    "lgcn_sample_negative_by_user": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "lgcn_np_seed": (None, [C.c_uint32]),
+    "lgcn_sample_python": (C.c_int64, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp]),
+    "lgcn_np_shuffle_perm": (C.c_int, [C.c_int64, _vp]),
+    "lgcn_build_user_item_csr": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lgcn_adj_rowsum": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "lgcn_build_norm_adj": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lgcn_spmm_csr": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "lgcn_propagate_mean": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "lgcn_apply_perm": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    "lgcn_ctx_create": (C.c_int, [C.POINTER(TrainConfig), C.POINTER(_vp)]),
+    "lgcn_ctx_destroy": (None, [_vp]),
+    "lgcn_ctx_get_step": (C.c_int64, [_vp]),
+    "lgcn_ctx_set_step": (None, [_vp, C.c_int64]),
+    "lgcn_ctx_set_lr": (None, [_vp, C.c_double]),
+    "lgcn_train_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    "lgcn_train_epoch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "lgcn_train_step_dp_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
+}
+
+_LIB = None
+
+
+class LgcnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (building first if the tree is newer) liblgcn_hip.so.  Raises if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if _build.is_stale():
+        if _build.find_hipcc() is not None:
+            _build.build()
+        elif not os.path.exists(path):
+            raise LgcnError(
+                f"liblgcn_hip.so is missing at {path} and hipcc is not available to build it. "
+                "The MI355X HIP library is the product path; there is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise LgcnError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LgcnError(f"{path} does not export {name} (stale build?)") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.lgcn_abi_version() != 1:
+        raise LgcnError("liblgcn_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().lgcn_last_error()
+        raise LgcnError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def npp(a):
+    """numpy array -> void* (array must stay alive for the call)."""
+    return a.ctypes.data_as(_vp)
+
+
+def tp(t):
+    """torch tensor -> void* device/host pointer."""
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available() or not load().lgcn_device_available():
+        raise LgcnError("no MI355X/HIP device visible: the LightGCN HIP kernels cannot run "
+                        "(there is deliberately no CPU fallback)")
+
+
+def current_stream():
+    import torch
+    return _vp(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,328 @@
+"""LightGCN, mirror of the reference's model.py (model.py:37-231) for the hot path.
+
+Same constructor `(config, dataset)`, same parameters (`embedding_user.weight`
+[n_users,d], `embedding_item.weight` [m_items,d] -> same state_dict keys), same
+methods (`computer`, `getEmbedding`, `bpr_loss`, `getUsersRating`, `forward`) plus
+the optional `invalidate_cache()` hook main.py:190-191 probes for.
+
+All propagation / loss / optimiser arithmetic runs in the hand-written gfx950
+kernels behind include/lgcn_hip.h.  There is no torch.sparse.mm path and no CPU
+fallback: on a machine without a HIP device every compute method raises.
+
+Out of scope: the popularity gate and the item-item
+smoothing branch; asking for them raises NotImplementedError.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import world
+from . import _lib
+
+
+def _act_code(name):
+    return {'fp32': _lib.F32, 'bf16': _lib.BF16}[name]
+
+
+class _Propagate(torch.autograd.Function):
+    """computer() with autograd: forward = lgcn_propagate_mean, backward = the Horner
+    chain (1/(K+1)) * sum_k A^k g through lgcn_spmm_csr (A_hat is symmetric)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, model):
+        ctx.model = model
+        return model._propagate_dense()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m = ctx.model
+        g = (grad_out.contiguous().float() / float(m.n_layers + 1))
+        h = g
+        for _ in range(m.n_layers):
+            h = g + m._spmm(h)
+        return h[:m.n_users], h[m.n_users:], None
+
+
+class LightGCN(nn.Module):
+    def __init__(self, config, dataset):
+        super().__init__()
+        self.config = config
+        self.dataset = dataset
+        self.device = world.device
+        self.n_users = dataset.n_users
+        self.m_items = dataset.m_items
+        self.latent_dim = config['latent_dim_rec']
+        self.n_layers = config['lightGCN_n_layers']
+        self.keep_prob = config.get('keep_prob', 0.6)
+        if bool(config.get('use_pop_gate', False)):
+            raise NotImplementedError("popularity gate (model.py:66-96) is outside the MI355X hot path")
+        if bool(config.get('use_item_item', False)) and config.get('i2i_path', None):
+            raise NotImplementedError("item-item smoothing (model.py:99-109) is outside the MI355X hot path")
+        self.use_pop_gate = False
+        self.use_item_item = False
+        if self.latent_dim not in (32, 64, 128, 256):
+            raise ValueError("latent_dim_rec must be 32, 64, 128 or 256 for the HIP kernels")
+        if not (1 <= self.n_layers <= _lib.MAX_LAYERS):
+            raise ValueError(f"lightGCN_n_layers must be in 1..{_lib.MAX_LAYERS}")
+
+        # Same RNG consumption as model.py:57-60 (two nn.Embedding ctors, then two normal_),
+        # then both tables are moved into ONE contiguous [N,d] storage: rows [0,n_users) are
+        # embedding_user.weight, rows [n_users,N) embedding_item.weight (the cat of model.py:209
+        # becomes a no-op).
+        self.embedding_user = nn.Embedding(self.n_users, self.latent_dim)
+        self.embedding_item = nn.Embedding(self.m_items, self.latent_dim)
+        nn.init.normal_(self.embedding_user.weight, std=0.1)
+        nn.init.normal_(self.embedding_item.weight, std=0.1)
+        with torch.no_grad():
+            table = torch.cat([self.embedding_user.weight, self.embedding_item.weight], dim=0).contiguous()
+        self._table = table
+        self._rebind()
+
+        self._adj = dataset.getSparseGraphCSR() if hasattr(dataset, 'getSparseGraphCSR') else None
+        if self._adj is None:                       # generic BasicDataset: COO -> CSR
+            g = dataset.getSparseGraph().coalesce().cpu()
+            import scipy.sparse as sp
+            idx = g.indices().numpy()
+            self._adj = sp.csr_matrix((g.values().numpy().astype(np.float32), (idx[0], idx[1])),
+                                      shape=tuple(g.shape))
+            self._adj.sort_indices()
+        N = self.n_users + self.m_items
+        if self._adj.shape != (N, N):
+            raise ValueError("adjacency shape does not match n_users + m_items")
+        if len(self._adj.indices) and (self._adj.indices.min() < 0 or self._adj.indices.max() >= N):
+            raise ValueError("adjacency column index out of range")
+        self._Graph = None
+        self._dev = None            # device-side state (graph, workspace, context)
+        self._cache = None          # propagated embeddings memoised between invalidate_cache() calls
+        self.f = nn.Sigmoid()
+
+    # -- parameters live in one table ------------------------------------------------
+    def _rebind(self):
+        self.embedding_user.weight.data = self._table[:self.n_users]
+        self.embedding_item.weight.data = self._table[self.n_users:]
+
+    def _apply(self, fn, recurse=True):
+        # keep the single-storage invariant through .to()/.cuda()/.float()
+        new = fn(self._table)
+        if new is not self._table:
+            self._table = new
+            self._drop_device_state()
+        self._rebind()
+        for p in (self.embedding_user.weight, self.embedding_item.weight):
+            if p.grad is not None:
+                p.grad = fn(p.grad)
+        return self
+
+    def _check_table(self):
+        """state_dict loads and optimisers write through the parameter views; make sure
+        nobody replaced them by independent tensors."""
+        u, i = self.embedding_user.weight, self.embedding_item.weight
+        if (u.data_ptr() != self._table.data_ptr()
+                or i.data_ptr() != self._table.data_ptr() + self.n_users * self.latent_dim * 4):
+            with torch.no_grad():
+                self._table[:self.n_users].copy_(u.data)
+                self._table[self.n_users:].copy_(i.data)
+            self._rebind()
+
+    @property
+    def Graph(self):
+        """torch sparse COO of A_hat as the reference keeps it (model.py:63); built lazily."""
+        if self._Graph is None:
+            self._Graph = self.dataset.getSparseGraph()
+        return self._Graph
+
+    # -- device state -----------------------------------------------------------------
+    def _drop_device_state(self):
+        if self._dev is not None and self._dev.get('ctx'):
+            _lib.load().lgcn_ctx_destroy(self._dev['ctx'])
+        self._dev = None
+        self._cache = None
+
+    def __del__(self):
+        try:
+            self._drop_device_state()
+        except Exception:
+            pass
+
+    def _state(self, max_batch=None, need_ctx=False, dp_world=1):
+        _lib.require_gpu()
+        if not self._table.is_cuda:
+            raise _lib.LgcnError("model parameters are not on the GPU: call .to(world.device) first")
+        self._check_table()
+        dev = self._table.device
+        if self._dev is None:
+            a = self._adj
+            self._dev = {
+                'indptr': torch.from_numpy(np.ascontiguousarray(a.indptr, np.int32)).to(dev),
+                'indices': torch.from_numpy(np.ascontiguousarray(a.indices, np.int32)).to(dev),
+                'vals': torch.from_numpy(np.ascontiguousarray(a.data, np.float32)).to(dev),
+                'ctx': None, 'max_batch': 0,
+            }
+        st = self._dev
+        if need_ctx:
+            max_batch = int(max_batch or self.config.get('bpr_batch_size', 2048))
+            if st['ctx'] is None or st['max_batch'] < max_batch or st.get('dp_world', 1) != dp_world:
+                self._make_ctx(max_batch, dp_world)
+        return st
+
+    def _make_ctx(self, max_batch, dp_world):
+        st, dev = self._dev, self._table.device
+        lib = _lib.load()
+        old_step = 0
+        if st['ctx'] is not None:
+            old_step = lib.lgcn_ctx_get_step(st['ctx'])
+            lib.lgcn_ctx_destroy(st['ctx'])
+            st['ctx'] = None
+        N, d, K = self.n_users + self.m_items, self.latent_dim, self.n_layers
+        act_dtype = _act_code(self.config.get('act_dtype', 'fp32'))
+        tdt = torch.float32 if act_dtype == _lib.F32 else torch.bfloat16
+        if 'adam_m' not in st:
+            st['adam_m'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
+            st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
+        st['act'] = torch.zeros(max(1, K - 1), N, d, dtype=tdt, device=dev)
+        st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
+        st['Gs'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
+        st['bitmap'] = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
+        st['terms'] = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
+        shard = (max_batch + dp_world - 1) // dp_world
+        st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
+        st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
+        cfg = _lib.TrainConfig()
+        cfg.indptr, cfg.indices, cfg.vals = st['indptr'].data_ptr(), st['indices'].data_ptr(), st['vals'].data_ptr()
+        cfg.N, cfg.nnz, cfg.n_users, cfg.d, cfg.K = N, int(st['indices'].numel()), self.n_users, d, K
+        cfg.act_dtype = act_dtype
+        cfg.E0, cfg.adam_m, cfg.adam_v = self._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
+        cfg.act, cfg.G64, cfg.Gs = st['act'].data_ptr(), st['G64'].data_ptr(), st['Gs'].data_ptr()
+        cfg.bitmap, cfg.terms, cfg.contrib = st['bitmap'].data_ptr(), st['terms'].data_ptr(), st['contrib'].data_ptr()
+        cfg.err, cfg.max_batch = st['err'].data_ptr(), max_batch
+        cfg.decay = float(self.config.get('decay', 1e-4))
+        cfg.lr = float(self.config.get('lr', 1e-3))
+        cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.999, 1e-8
+        cfg.xcd_remap = int(self.config.get('xcd_remap', 1))
+        h = C.c_void_p()
+        _lib.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "lgcn_ctx_create")
+        lib.lgcn_ctx_set_step(h, old_step)
+        st['ctx'], st['max_batch'], st['dp_world'], st['table_ptr'] = h, max_batch, dp_world, self._table.data_ptr()
+
+    # -- kernels ------------------------------------------------------------------------
+    def _spmm(self, x):
+        st = self._state()
+        x = x.contiguous()
+        y = torch.empty_like(x, dtype=torch.float32)
+        N = self.n_users + self.m_items
+        _lib.check(_lib.load().lgcn_spmm_csr(_lib.tp(st['indptr']), _lib.tp(st['indices']), _lib.tp(st['vals']), N,
+                                             _lib.tp(x.float()), _lib.F32, _lib.tp(y), _lib.F32, self.latent_dim,
+                                             _lib.current_stream()), "lgcn_spmm_csr")
+        return y
+
+    def _propagate_dense(self):
+        st = self._state()
+        N, d, K = self.n_users + self.m_items, self.latent_dim, self.n_layers
+        act_dtype = _act_code(self.config.get('act_dtype', 'fp32'))
+        tdt = torch.float32 if act_dtype == _lib.F32 else torch.bfloat16
+        work = st.get('eval_work')
+        if K > 1 and (work is None or work.dtype != tdt):
+            work = st['eval_work'] = torch.empty(K - 1, N, d, dtype=tdt, device=self._table.device)
+        out = torch.empty(N, d, dtype=torch.float32, device=self._table.device)
+        _lib.check(_lib.load().lgcn_propagate_mean(
+            _lib.tp(st['indptr']), _lib.tp(st['indices']), _lib.tp(st['vals']), N, _lib.tp(self._table), K, d,
+            act_dtype, _lib.tp(work) if K > 1 else None, _lib.tp(out), _lib.current_stream()),
+            "lgcn_propagate_mean")
+        return out
+
+    # -- reference API --------------------------------------------------------------------
+    def invalidate_cache(self):
+        """Hook probed by main.py:190-191 before each Test."""
+        self._cache = None
+
+    def train(self, mode=True):
+        self._cache = None
+        return super().train(mode)
+
+    def computer(self):
+        """model.py:201-231 -> (all_users [n_users,d], all_items [m_items,d])."""
+        if not self.training and not torch.is_grad_enabled():
+            if self._cache is None:            # eval: propagate once instead of once per user batch
+                self._cache = self._propagate_dense()
+            out = self._cache
+        elif torch.is_grad_enabled() and (self.embedding_user.weight.requires_grad
+                                          or self.embedding_item.weight.requires_grad):
+            out = _Propagate.apply(self.embedding_user.weight, self.embedding_item.weight, self)
+        else:
+            out = self._propagate_dense()
+        return out[:self.n_users, :], out[self.n_users:, :]
+
+    def getUsersRating(self, users):
+        all_users, all_items = self.computer()
+        u_emb = all_users[users]
+        return torch.matmul(u_emb, all_items.t())
+
+    def getEmbedding(self, users, pos_items, neg_items):
+        all_users, all_items = self.computer()
+        return all_users[users], all_items[pos_items], all_items[neg_items], all_users, all_items
+
+    def bpr_loss(self, users, pos, neg):
+        """model.py:162-183 (unfused, autograd-capable): (bpr, reg_loss)."""
+        u, pos_e, neg_e, _, _ = self.getEmbedding(users, pos, neg)
+        pos_scores = torch.sum(u * pos_e, dim=1)
+        neg_scores = torch.sum(u * neg_e, dim=1)
+        bpr = -torch.mean(F.logsigmoid(pos_scores - neg_scores))
+        reg_loss = (0.5 * (u.norm(2).pow(2) + pos_e.norm(2).pow(2) + neg_e.norm(2).pow(2))) / float(u.shape[0])
+        return bpr, reg_loss
+
+    def forward(self, users, items):
+        all_users, all_items = self.computer()
+        return (all_users[users] * all_items[items]).sum(dim=1)
+
+    # -- fused path (what BPRLoss.stageOne calls) ------------------------------------------
+    @staticmethod
+    def _ids(t, dev):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=dev, dtype=torch.int32).contiguous()
+
+    def fused_step(self, users, pos, neg, loss_out=None, lr=None):
+        """One BPRLoss.stageOne (utils.py:53-64) in the HIP kernels.  Returns a device
+        tensor [3] = (bpr + decay*reg, bpr, reg); no host synchronisation."""
+        dev = self._table.device
+        users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
+        B = int(users.numel())
+        st = self._state(max_batch=max(B, int(self.config.get('bpr_batch_size', B))), need_ctx=True,
+                         dp_world=(self._dev or {}).get('dp_world', 1))
+        lib = _lib.load()
+        if lr is not None:
+            lib.lgcn_ctx_set_lr(st['ctx'], float(lr))
+        if loss_out is None:
+            loss_out = torch.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.lgcn_train_step(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
+                                       _lib.tp(loss_out), _lib.current_stream()), "lgcn_train_step")
+        self._cache = None
+        return loss_out
+
+    def fused_epoch(self, users, pos, neg, batch_size, lr=None):
+        """The loop of main.py:223-225 over already-shuffled device id arrays, one C call.
+        Returns a device tensor [steps,3] of per-step (loss, bpr, reg)."""
+        dev = self._table.device
+        users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
+        T = int(users.numel())
+        steps = (T + batch_size - 1) // batch_size
+        st = self._state(max_batch=batch_size, need_ctx=True, dp_world=(self._dev or {}).get('dp_world', 1))
+        lib = _lib.load()
+        if lr is not None:
+            lib.lgcn_ctx_set_lr(st['ctx'], float(lr))
+        losses = torch.empty(steps, 3, dtype=torch.float32, device=dev)
+        _lib.check(lib.lgcn_train_epoch(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), T, int(batch_size),
+                                        _lib.tp(losses), _lib.current_stream()), "lgcn_train_epoch")
+        self._cache = None
+        return losses
+
+    def check_device_errors(self):
+        if self._dev and self._dev.get('ctx'):
+            _lib.check(_lib.load().lgcn_ctx_check(self._dev['ctx'], _lib.current_stream()), "device id check")
+
+    @property
+    def adam_step(self):
+        return _lib.load().lgcn_ctx_get_step(self._dev['ctx']) if self._dev and self._dev.get('ctx') else 0

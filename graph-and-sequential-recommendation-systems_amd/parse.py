@@ -1,0 +1,71 @@
+"""Flag surface of the reference's parse.py (parse.py:16-114): the same 34 flags
+with the same names, types and defaults, plus additive flags (marked NEW) whose
+defaults reproduce the reference's behaviour."""
+import argparse
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Go LightGCN")
+    # core training parameters                                    parse.py:20-37
+    p.add_argument('--bpr_batch', type=int, default=2048)
+    p.add_argument('--recdim', type=int, default=64)
+    p.add_argument('--layer', type=int, default=3)
+    p.add_argument('--lr', type=float, default=0.001)
+    p.add_argument('--decay', type=float, default=1e-4)
+    p.add_argument('--dropout', type=int, default=0)
+    p.add_argument('--keepprob', type=float, default=0.6)
+    p.add_argument('--epochs', type=int, default=1000)
+    p.add_argument('--testbatch', type=int, default=100)
+    # dataset & paths                                              parse.py:40-45
+    p.add_argument('--dataset', type=str, default='gowalla')
+    p.add_argument('--checkpoint_dir', type=str, default='./checkpoints')
+    p.add_argument('--topks', type=str, default='[20]')
+    # logging & reproducibility                                    parse.py:48-61
+    p.add_argument('--tensorboard', type=int, default=1)
+    p.add_argument('--comment', type=str, default='lgn')
+    p.add_argument('--load', type=int, default=0)
+    p.add_argument('--pretrain', type=int, default=0)
+    p.add_argument('--seed', type=int, default=2020)
+    p.add_argument('--model', type=str, default='lgn')
+    p.add_argument('--a_fold', type=int, default=100)
+    p.add_argument('--A_split', dest='A_split', action='store_true')
+    p.add_argument('--no-A_split', dest='A_split', action='store_false')
+    p.set_defaults(A_split=False)
+    # global smoothing / PPR                                       parse.py:69-74
+    p.add_argument('--exp_smooth_beta', type=float, default=0.5)
+    p.add_argument('--use_ppr_weights', action='store_true')
+    p.add_argument('--ppr_weights_path', type=str, default=None)
+    # scheduler                                                    parse.py:77-82
+    p.add_argument('--use_scheduler', action='store_true')
+    p.add_argument('--sched_milestones', type=str, default='[120,240,360,480]')
+    p.add_argument('--sched_gamma', type=float, default=0.5)
+    # popularity gate                                              parse.py:85-94
+    p.add_argument('--use_pop_gate', action='store_true')
+    p.add_argument('--pop_hidden', type=int, default=32)
+    p.add_argument('--gate_hidden', type=int, default=64)
+    p.add_argument('--gate_entropy_coeff', type=float, default=1e-4)
+    p.add_argument('--pop_gate_temp', type=float, default=1.0)
+    # item-item adjacency                                          parse.py:97-102
+    p.add_argument('--use_item_item', action='store_true')
+    p.add_argument('--i2i_path', type=str, default=None)
+    p.add_argument('--i2i_alpha', type=float, default=0.0)
+    # miscellaneous                                                parse.py:105-112
+    p.add_argument('--multicore', type=int, default=0)
+    p.add_argument('--resume', action='store_true')
+    p.add_argument('--resume_path', type=str, default=None)
+    p.add_argument('--save_every', type=int, default=10)
+    # ---- NEW (additive) ----------------------------------------------------
+    p.add_argument('--sampler', type=str, default='auto', choices=['auto', 'cpp', 'python'],
+                   help="NEW: 'cpp' = sampling.cpp stream, 'python' = numpy fallback stream, "
+                        "'auto' = cpp unless a user has no positives")
+    p.add_argument('--act_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
+                   help='NEW: storage type of propagated layer activations (accumulation is fp32)')
+    p.add_argument('--xcd_remap', type=int, default=1,
+                   help='NEW: give every XCD a contiguous range of graph rows')
+    p.add_argument('--data_path', type=str, default=None,
+                   help='NEW: directory that holds <dataset>/train.txt (default: <root>/data)')
+    return p
+
+
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)

@@ -1,0 +1,254 @@
+"""Training utilities, mirror of the reference's utils.py (utils.py:25-217).
+
+BPRLoss.stageOne runs the fused HIP step; the samplers and the epoch shuffle run
+the native bit-exact restatements (glibc rand() / numpy legacy MT19937 streams)."""
+import os
+from time import time
+
+import numpy as np
+import torch
+from torch import nn, optim
+
+from . import world
+from . import _lib
+from .dataloader import BasicDataset
+
+# ==================== Negative Sampling Extension ====================
+# utils.py:25-34 binds the cppimport-built module `sampling` and seeds it with world.seed;
+# here the same four functions come from liblgcn_hip.so.
+try:
+    from . import sampling
+    sampling.seed(world.seed)
+    sample_ext = True
+except Exception as _e:           # library missing: say so (the reference falls back silently)
+    world.cprint(f"Cpp extension not loaded: {_e}")
+    sample_ext = False
+
+
+class _AdamView(optim.Adam):
+    """torch.optim.Adam whose state tensors are views of the fused kernel's m/v tables, so
+    `bpr.opt` keeps the reference's surface (param_groups[0]['lr'], state_dict(),
+    load_state_dict(), LR schedulers -- main.py:36,61,197) while the update itself happens
+    in the epilogue of the last backward SpMM."""
+
+    def bind(self, model):
+        self._model = model
+        return self
+
+    def _sync_from_kernel(self):
+        m = self._model
+        st = m._dev
+        if not st or 'adam_m' not in st:
+            return
+        nu = m.n_users
+        step = float(m.adam_step)
+        for p, sl in ((m.embedding_user.weight, slice(0, nu)), (m.embedding_item.weight, slice(nu, None))):
+            s = self.state[p]
+            s['step'] = torch.tensor(step, dtype=torch.float32)
+            s['exp_avg'], s['exp_avg_sq'] = st['adam_m'][sl], st['adam_v'][sl]
+
+    def state_dict(self):
+        self._sync_from_kernel()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        m = self._model
+        st = m._state(need_ctx=True)
+        nu = m.n_users
+        step = 0
+        with torch.no_grad():
+            for p, sl in ((m.embedding_user.weight, slice(0, nu)), (m.embedding_item.weight, slice(nu, None))):
+                s = self.state.get(p, {})
+                if 'exp_avg' in s:
+                    st['adam_m'][sl].copy_(s['exp_avg'])
+                    st['adam_v'][sl].copy_(s['exp_avg_sq'])
+                    step = int(float(s['step']))
+        _lib.load().lgcn_ctx_set_step(st['ctx'], step)
+        self._sync_from_kernel()
+
+    def step(self, closure=None):
+        raise RuntimeError("the Adam update is fused into BPRLoss.stageOne (HIP kernel epilogue); "
+                           "call stageOne, or build a plain torch.optim.Adam for an unfused loop")
+
+
+class BPRLoss:
+    """utils.py:38-64."""
+
+    def __init__(self, recmodel: nn.Module, config: dict):
+        self.model = recmodel
+        self.weight_decay = config['decay']
+        self.lr = config['lr']
+        self.opt = _AdamView(recmodel.parameters(), lr=self.lr).bind(recmodel)
+        recmodel.config['decay'] = self.weight_decay
+        self.lazy = False          # True: stageOne returns a 0-dim device tensor (no host sync)
+
+    def stageOne(self, users, pos, neg):
+        lr = self.opt.param_groups[0]['lr']
+        out = self.model.fused_step(users, pos, neg, lr=lr)
+        if self.lazy:
+            return out[0]
+        return out[0].cpu().item()                 # utils.py:64 (host sync per step)
+
+
+# ==================== Sampling ====================
+def _pos_csr(dataset):
+    if hasattr(dataset, 'pos_csr'):
+        return dataset.pos_csr()
+    return sampling._csr_of(dataset.allPos)
+
+
+def sampler_mode(dataset):
+    """'cpp' / 'python' per --sampler; 'auto' picks cpp unless a user has no positives
+    (where the reference's native sampler dies with SIGFPE)."""
+    mode = world.config.get('sampler', 'auto')
+    if mode == 'auto':
+        if not sample_ext:
+            return 'python'
+        indptr, _ = _pos_csr(dataset)
+        return 'python' if np.any(np.diff(indptr[:dataset.n_users + 1]) == 0) else 'cpp'
+    return mode
+
+
+def UniformSample_original(dataset, neg_ratio=1):
+    """utils.py:68-81."""
+    dataset: BasicDataset
+    if sample_ext and sampler_mode(dataset) == 'cpp':
+        S = sampling.sample_negative(dataset.n_users, dataset.m_items, dataset.trainDataSize,
+                                     _pos_csr(dataset), neg_ratio)
+    else:
+        S = UniformSample_original_python(dataset)
+    return S
+
+
+def UniformSample_original_python(dataset):
+    """utils.py:84-110 on the numpy-legacy stream (native, bit-exact): int64 [<=trainDataSize,3]."""
+    indptr, indices = _pos_csr(dataset)
+    S = np.empty((dataset.trainDataSize, 3), np.int64)
+    rows = _lib.load().lgcn_sample_python(dataset.n_users, dataset.m_items, dataset.trainDataSize,
+                                          _lib.npp(indptr), _lib.npp(indices), _lib.npp(S))
+    if rows < 0:
+        _lib.check(1, "lgcn_sample_python")
+    return S[:rows]
+
+
+# ==================== Utility helpers ====================
+def set_seed(seed):
+    """utils.py:114-120; the numpy legacy stream lives in the native library."""
+    np.random.seed(seed)
+    _lib.load().lgcn_np_seed(int(seed) & 0xFFFFFFFF)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+    torch.manual_seed(seed)
+
+
+def getFileName():
+    """utils.py:123-132."""
+    if world.model_name == 'mf':
+        file = f"mf-{world.dataset}-{world.config['latent_dim_rec']}.pth.tar"
+    elif world.model_name == 'lgn':
+        file = f"lgn-{world.dataset}-{world.config['lightGCN_n_layers']}-{world.config['latent_dim_rec']}.pth.tar"
+    return os.path.join(world.PATH, file)
+
+
+def minibatch(*tensors, **kwargs):
+    """utils.py:135-139 (always yields a tuple, like the fork)."""
+    batch_size = kwargs.get('batch_size', world.config['bpr_batch_size'])
+    for i in range(0, len(tensors[0]), batch_size):
+        yield tuple(x[i:i + batch_size] for x in tensors)
+
+
+def shuffle_indices(n):
+    """idx = np.arange(n); np.random.shuffle(idx) on the native numpy-legacy stream."""
+    perm = np.empty(n, np.int64)
+    _lib.check(_lib.load().lgcn_np_shuffle_perm(n, _lib.npp(perm)), "lgcn_np_shuffle_perm")
+    return perm
+
+
+def shuffle(*arrays, **kwargs):
+    """utils.py:142-151."""
+    require_indices = kwargs.get('indices', False)
+    if len(set(len(x) for x in arrays)) != 1:
+        raise ValueError("All inputs must have same length.")
+    idx = shuffle_indices(len(arrays[0]))
+    result = []
+    for x in arrays:
+        if torch.is_tensor(x):
+            result.append(x[torch.from_numpy(idx).to(x.device)])
+        else:
+            result.append(x[idx])
+    result = tuple(result)
+    return (result, idx) if require_indices else result
+
+
+class timer:
+    """Context-manager timer with named accumulators -- the API Procedure.py:50,81-82 expects
+    (the fork's own utils.timer lost it)."""
+    TAPE = [-1]
+    NAMED_TAPE = {}
+
+    @staticmethod
+    def get():
+        return timer.TAPE.pop() if len(timer.TAPE) > 1 else -1
+
+    @staticmethod
+    def dict(select_keys=None):
+        hint = "|"
+        keys = timer.NAMED_TAPE.keys() if select_keys is None else select_keys
+        for key in keys:
+            hint = hint + f"{key}:{timer.NAMED_TAPE[key]:.2f}|"
+        return hint
+
+    @staticmethod
+    def zero(select_keys=None):
+        for key in (timer.NAMED_TAPE.keys() if select_keys is None else select_keys):
+            timer.NAMED_TAPE[key] = 0
+
+    def __init__(self, tape=None, **kwargs):
+        if kwargs.get('name'):
+            timer.NAMED_TAPE[kwargs['name']] = timer.NAMED_TAPE.get(kwargs['name'], 0.)
+            self.named = kwargs['name']
+        else:
+            self.named = False
+            self.tape = tape or timer.TAPE
+
+    def __enter__(self):
+        self.start = time()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        if self.named:
+            timer.NAMED_TAPE[self.named] += time() - self.start
+        else:
+            self.tape.append(time() - self.start)
+
+
+# ==================== Evaluation Metrics (utils.py:173-217) ====================
+def RecallPrecision_ATk(test_data, r, k):
+    right_pred = r[:, :k].sum(1)
+    precis_n = k
+    recall_n = np.array([len(test_data[i]) for i in range(len(test_data))])
+    recall = np.sum(right_pred / recall_n)
+    precis = np.sum(right_pred) / precis_n
+    return {'recall': recall, 'precision': precis}
+
+
+def NDCGatK_r(test_data, r, k):
+    assert len(r) == len(test_data)
+    pred_data = r[:, :k]
+    test_matrix = np.zeros((len(pred_data), k))
+    for i, items in enumerate(test_data):
+        test_matrix[i, :min(k, len(items))] = 1
+    idcg = np.sum(test_matrix * 1. / np.log2(np.arange(2, k + 2)), axis=1)
+    dcg = np.sum(pred_data * (1. / np.log2(np.arange(2, k + 2))), axis=1)
+    idcg[idcg == 0.] = 1.
+    ndcg = dcg / idcg
+    return np.sum(ndcg)
+
+
+def getLabel(groundTruth, predictTopK):
+    if not isinstance(groundTruth, (list, set, tuple, np.ndarray)):
+        groundTruth = [groundTruth]
+    pred = [1.0 if x in groundTruth else 0.0 for x in predictTopK]
+    return np.array(pred, dtype=np.float32)

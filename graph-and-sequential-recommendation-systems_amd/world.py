@@ -1,0 +1,108 @@
+"""Global configuration, mirror of the reference's world.py (world.py:26-109): the
+same module-level globals and the same `config` keys.  Like the reference it
+parses sys.argv when first imported; unlike it, an argv it cannot parse (e.g.
+when imported under pytest) falls back to the defaults instead of exiting, and
+`configure(argv)` re-parses explicitly."""
+import ast
+import multiprocessing
+import os
+import sys
+from os.path import dirname, join
+
+import torch
+
+from .parse import parse_args
+
+os.environ.setdefault('KMP_DUPLICATE_LIB_OK', 'True')
+
+
+def cprint(*args_, **kwargs):
+    print(*args_, **kwargs)
+
+
+try:
+    CORES = multiprocessing.cpu_count() // 2
+except Exception:
+    CORES = 4
+
+ROOT_PATH = dirname(dirname(os.path.abspath(__file__)))
+CODE_PATH = join(ROOT_PATH, 'code')
+DATA_PATH = join(ROOT_PATH, 'data')
+BOARD_PATH = join(CODE_PATH, 'runs')
+
+config = {}
+ARGV_ERROR = None
+
+
+def configure(argv=None):
+    """(Re)parse flags and refresh every global + `config` in place."""
+    global args, seed, dataset, comment, tensorboard, LOAD, model_name, TRAIN_epochs, topks
+    global PATH, DATA_PATH, device
+    args = parse_args(argv)
+    seed = args.seed
+    dataset = args.dataset
+    comment = args.comment
+    tensorboard = args.tensorboard
+    LOAD = args.load
+    model_name = args.model
+    TRAIN_epochs = args.epochs
+    topks = ast.literal_eval(args.topks) if isinstance(args.topks, str) else args.topks
+    PATH = args.checkpoint_dir
+    if args.data_path:
+        DATA_PATH = args.data_path
+    config.clear()
+    config.update({
+        'checkpoint_dir': PATH,
+        'dataset': args.dataset,
+        'lr': args.lr,
+        'decay': args.decay,
+        'lightGCN_n_layers': args.layer,
+        'latent_dim_rec': args.recdim,
+        'bpr_batch_size': args.bpr_batch,
+        'test_u_batch_size': args.testbatch,
+        'dropout': args.dropout,
+        'keep_prob': args.keepprob,
+        'A_split': args.A_split,
+        'A_n_fold': args.a_fold,
+        'epochs': args.epochs,
+        'multicore': args.multicore,
+        'pretrain': args.pretrain,
+        'seed': args.seed,
+        'model': args.model,
+        'exp_smooth_beta': args.exp_smooth_beta,
+        'use_ppr_weights': args.use_ppr_weights,
+        'ppr_weights_path': args.ppr_weights_path,
+        'use_scheduler': args.use_scheduler,
+        'sched_gamma': args.sched_gamma,
+    })
+    try:
+        config['sched_milestones'] = (list(map(int, ast.literal_eval(args.sched_milestones)))
+                                      if isinstance(args.sched_milestones, str)
+                                      else list(args.sched_milestones))
+    except Exception:
+        config['sched_milestones'] = [120, 240, 360, 480]
+    config['use_pop_gate'] = args.use_pop_gate
+    config['pop_hidden'] = args.pop_hidden
+    config['gate_hidden'] = args.gate_hidden
+    config['gate_entropy_coeff'] = args.gate_entropy_coeff
+    config['pop_gate_temp'] = args.pop_gate_temp
+    config['use_item_item'] = args.use_item_item
+    config['i2i_path'] = args.i2i_path
+    config['i2i_alpha'] = args.i2i_alpha
+    # keys the reference parses but never copies -- copied here
+    config['resume'] = args.resume
+    config['resume_path'] = args.resume_path
+    config['save_every'] = args.save_every
+    # NEW additive keys
+    config['sampler'] = args.sampler
+    config['act_dtype'] = args.act_dtype
+    config['xcd_remap'] = args.xcd_remap
+    device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+    return config
+
+
+try:
+    configure(None if len(sys.argv) > 0 else [])
+except SystemExit as _e:           # argv belongs to someone else (pytest, a launcher)
+    ARGV_ERROR = f"sys.argv not understood by parse.py (exit {_e.code}); defaults used"
+    configure([])

@@ -1,0 +1,190 @@
+/*
+ * lgcn_hip.h -- C ABI of the MI355X-native LightGCN/BPR training hot path.
+ *
+ * One shared library (liblgcn_hip.so, built from
+ * graph-and-sequential-recommendation-systems_amd/csrc by hipcc for gfx950).
+ * Plain C types only: device buffers are raw pointers (e.g. torch
+ * `tensor.data_ptr()`), streams are `hipStream_t` passed as void*.  Every
+ * device entry point is asynchronous on the given stream, never allocates,
+ * never synchronises, and is therefore hipGraph-capturable.  Return value:
+ * 0 = ok, non-zero = error (text via lgcn_last_error()).
+ *
+ * Each entry point names the reference interface it replaces; paths are
+ * relative to LightGCN_work/code in saamiya225/Graph-and-sequential-recommendation-systems.
+ * The reference's only FFI on this path is the pybind11 module `sampling`
+ * (sources/sampling.cpp:95-106); everything else replaces PyTorch library
+ * calls made from model.py / utils.py.  INTEGRATION.md shows the bindings.
+ */
+#ifndef LGCN_HIP_H
+#define LGCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGCN_ABI_VERSION 1
+#define LGCN_MAX_LAYERS 8
+
+/* storage type of propagated activations (accumulation is always fp32) */
+enum { LGCN_F32 = 0, LGCN_BF16 = 1 };
+
+int lgcn_abi_version(void);
+const char *lgcn_last_error(void);
+/* 1 if a HIP device is usable from this process, else 0 (never throws) */
+int lgcn_device_available(void);
+
+/* ------------------------------------------------------------------------ */
+/* Host: BPR triplet sampler -- replaces the pybind11 module `sampling`      */
+/* ------------------------------------------------------------------------ */
+/* sampling.seed(seed)            sources/sampling.cpp:88-91,101  (srand)     */
+void lgcn_sampling_seed(unsigned int seed);
+/* sampling.randint(end)          sources/sampling.cpp:22-25,100  (rand()%end) */
+int lgcn_sampling_randint(int end);
+/* sampling.sample_negative(user_num,item_num,train_num,allPos,neg_num)
+ *                                sources/sampling.cpp:27-56,102-103
+ * allPos is passed zero-copy as the CSR (indptr[user_num+1], indices) of
+ * UserItemNet (dataloader.py:133-136,178-180; columns sorted ascending).
+ * S_out: int32 [user_num*(train_num/user_num), 2+neg_num], row-major.
+ * Bit-exact glibc rand() stream.  Returns 2 (no crash) if a user has no
+ * positives, where the reference dies with SIGFPE on rand()%0. */
+int lgcn_sample_negative(int user_num, int item_num, int64_t train_num,
+                         const int64_t *indptr, const int32_t *indices,
+                         int neg_num, int32_t *S_out);
+/* sampling.sample_negative_ByUser(users,item_num,allPos,neg_num)
+ *                                sources/sampling.cpp:58-86,104-105          */
+int lgcn_sample_negative_by_user(const int32_t *users, int n_users_listed, int item_num,
+                                 const int64_t *indptr, const int32_t *indices,
+                                 int neg_num, int32_t *S_out);
+
+/* numpy legacy global RandomState stream (MT19937), used by the reference for
+ * the fallback sampler and the epoch shuffle.                                 */
+/* utils.set_seed -> np.random.seed(seed)                    utils.py:114-120 */
+void lgcn_np_seed(uint32_t seed);
+/* utils.UniformSample_original_python                       utils.py:84-110
+ * S_out: int64 [train_num,3]; returns the number of rows written (users with no
+ * positives are skipped), or -1 on error.                                      */
+int64_t lgcn_sample_python(int n_users, int m_items, int64_t train_num,
+                           const int64_t *indptr, const int32_t *indices, int64_t *S_out);
+/* utils.shuffle: idx = arange(n); np.random.shuffle(idx)    utils.py:148-149 */
+int lgcn_np_shuffle_perm(int64_t n, int64_t *perm_out);
+
+/* ------------------------------------------------------------------------ */
+/* Host: graph builder -- replaces Loader.getSparseGraph dataloader.py:218-234 */
+/* ------------------------------------------------------------------------ */
+/* COO interactions (dataloader.py:133-136) -> UserItemNet CSR with sorted,
+ * de-duplicated columns (values = multiplicity).  Call with indices==NULL to get
+ * the de-duplicated nnz in *nnz_out first.                                     */
+int lgcn_build_user_item_csr(int n_users, int m_items, int64_t n_inter,
+                             const int64_t *train_user, const int64_t *train_item,
+                             int64_t *indptr, int32_t *indices, float *vals, int64_t *nnz_out);
+/* fp32 row sums of A=[[0,R],[R^T,0]]                        dataloader.py:230 */
+int lgcn_adj_rowsum(int n_users, int m_items, const int64_t *r_indptr, const int32_t *r_indices,
+                    const float *r_vals, float *rowsum);
+/* A_hat = D^-1/2 A D^-1/2 as CSR (int32 indptr[N+1], indices[2E], fp32 data[2E]),
+ * value = fl32(fl32(d_inv[i]*a_ij)*d_inv[j]); d_inv is supplied by the caller
+ * (the host mirror computes it with numpy.power exactly as dataloader.py:231). */
+int lgcn_build_norm_adj(int n_users, int m_items, const int64_t *r_indptr, const int32_t *r_indices,
+                        const float *r_vals, const float *d_inv,
+                        int32_t *indptr, int32_t *indices, float *data);
+
+/* ------------------------------------------------------------------------ */
+/* Device: single kernels                                                     */
+/* ------------------------------------------------------------------------ */
+/* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217
+ * (and its autograd backward A^T g: A_hat is symmetric).  X,Y: [n_rows,d]
+ * row-major, fp32 or bf16 (x_dtype / y_dtype); d in {32,64,128,256}.           */
+int lgcn_spmm_csr(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t n_rows,
+                  const void *X, int x_dtype, void *Y, int y_dtype, int d, void *stream);
+
+/* out[N,d] fp32 = mean(X_0, A X_0, ..., A^K X_0) -- replaces LightGCN.computer()
+ * model.py:201-231 (cat + K sparse.mm + stack + mean).  work: (K-1)*N*d elements
+ * of act_dtype (may be NULL for K == 1).                                       */
+int lgcn_propagate_mean(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t N,
+                        const float *E0, int K, int d, int act_dtype, void *work, float *out,
+                        void *stream);
+
+/* users/pos/neg[T] = S[perm[t], 0..2] -- the device side of utils.shuffle
+ * (utils.py:150) applied to the sampler output (main.py:217-220).            */
+int lgcn_apply_perm(const int32_t *S, int s_cols, const int64_t *perm, int64_t T,
+                    int32_t *users, int32_t *pos, int32_t *neg, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Device: fused training step -- replaces BPRLoss.stageOne   utils.py:53-64  */
+/*   = LightGCN.bpr_loss (model.py:162-183) + loss.backward() (autograd of     */
+/*     model.py:201-231) + torch.optim.Adam.step (utils.py:51,62)              */
+/* ------------------------------------------------------------------------ */
+typedef struct lgcn_ctx lgcn_ctx;   /* opaque */
+
+typedef struct {
+    /* graph: CSR of A_hat on the device (dataloader.py:203-246) */
+    const int32_t *indptr;      /* [N+1] */
+    const int32_t *indices;     /* [nnz] */
+    const float *vals;          /* [nnz] */
+    int64_t N;                  /* n_users + m_items */
+    int64_t nnz;
+    int32_t n_users;
+    int32_t d;                  /* latent_dim_rec: 32/64/128/256 */
+    int32_t K;                  /* lightGCN_n_layers: 1..LGCN_MAX_LAYERS */
+    int32_t act_dtype;          /* LGCN_F32 | LGCN_BF16: storage of layer activations */
+    /* parameters + Adam state, fp32 [N,d]: rows [0,n_users) = embedding_user.weight,
+     * rows [n_users,N) = embedding_item.weight (model.py:57-60) */
+    float *E0;
+    float *adam_m;
+    float *adam_v;
+    /* workspace, caller-allocated, zero-initialised before the first step */
+    void *act;                  /* max(1,K-1) * N*d elements of act_dtype */
+    int64_t *G64;               /* [N,d] fixed-point gradient accumulator */
+    float *Gs;                  /* [N,d] sparse-row gradient G/(K+1) */
+    uint32_t *bitmap;           /* [ceil(N/32)] rows of Gs that are non-zero */
+    float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
+    float *contrib;             /* [3*max_batch*d + 2*max_batch] (data-parallel exchange buffer) or NULL */
+    int32_t *err;               /* [1] device error flag */
+    int32_t max_batch;
+    /* hyper-parameters (utils.py:47-51, torch.optim.Adam defaults) */
+    float decay;                /* config['decay'] */
+    double lr, beta1, beta2, eps;
+    int32_t xcd_remap;          /* 1: contiguous row ranges per XCD */
+    int32_t reserved;
+} lgcn_train_config;
+
+int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out);
+void lgcn_ctx_destroy(lgcn_ctx *ctx);
+/* optimizer step counter (torch Adam state['step']) for checkpoint/resume */
+int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx);
+void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t step);
+void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr);
+
+/* One full stageOne on a batch of B triplets (device int32 ids).
+ * loss_out[0..2] (device) = {bpr + decay*reg, bpr, reg}.  No host sync.        */
+int lgcn_train_step(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                    int32_t B, float *loss_out, void *stream);
+
+/* A whole epoch: the loop of main.py:223-225 over ceil(T/B) consecutive batches
+ * of the (already shuffled) device arrays.  loss_out: [3*ceil(T/B)].           */
+int lgcn_train_epoch(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                     int64_t T, int32_t B, float *loss_out, void *stream);
+
+/* Data-parallel split of the same step (replicated tables, batch sharded):
+ *   part 1  forward propagation + per-triplet loss terms and gradient rows for this
+ *           rank's shard [rank*S, min((rank+1)*S, B_global)), S = ceil(B_global/world),
+ *           written to cfg.contrib as [3*S*d gradient rows | S loss | S reg terms];
+ *   (caller: RCCL all-gather of that block over the ranks into `gathered`)
+ *   part 2  order-independent reduction of all ranks' rows, backward propagation
+ *           and Adam -- bitwise identical on every rank and to lgcn_train_step.  */
+int lgcn_train_step_dp_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
+                             const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
+                             void *stream);
+int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
+                             const int32_t *neg, int32_t B_global, int32_t world,
+                             const float *gathered, float *loss_out, void *stream);
+
+/* reads and clears the device error flag (synchronises the stream): 0 = none,
+ * 1 = id out of range in users/pos/neg.                                        */
+int lgcn_ctx_check(lgcn_ctx *ctx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGCN_HIP_H */

@@ -1,0 +1,336 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs, against the golden fixtures captured from the reference,
+and -- at full Gowalla size -- through size-independent properties.
+
+Tolerances (fp32 path): the GPU sums a CSR row in 4 interleaved partial sums with FMA, the
+oracle/reference sequentially without, so single SpMM outputs agree to ~1e-6 relative;
+per-step losses to 5e-6 absolute; parameters after an epoch to 1e-5 absolute; Recall/NDCG
+to 1e-4 (BASELINE.json north_star).  Integer work (sampler, shuffle, permutation apply) is
+bit-exact.  bf16 activation storage is a separate, looser mode (2e-2 relative on rows)."""
+import ctypes as C
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def _spmm(pkg, indptr, indices, vals, X, x_dtype=0, y_dtype=0):
+    L = pkg._lib
+    n, d = len(indptr) - 1, X.shape[1]
+    ip, ix, vv = _dev(indptr.astype(np.int32)), _dev(indices.astype(np.int32)), _dev(vals.astype(np.float32))
+    x = _dev(X.astype(np.float32))
+    if x_dtype == 1:
+        x = x.to(torch.bfloat16)
+    y = torch.empty(n, d, dtype=torch.float32 if y_dtype == 0 else torch.bfloat16, device=DEV)
+    L.check(L.load().lgcn_spmm_csr(L.tp(ip), L.tp(ix), L.tp(vv), n, L.tp(x), x_dtype, L.tp(y), y_dtype, d,
+                                   L.current_stream()), "spmm")
+    torch.cuda.synchronize()
+    return y.float().cpu().numpy()
+
+
+def _random_graph(rng, n, avg_deg, heavy=0):
+    deg = rng.poisson(avg_deg, n).astype(np.int64)
+    deg[rng.integers(0, n, max(1, n // 50))] = 0            # empty rows
+    for _ in range(heavy):
+        deg[rng.integers(0, n)] = min(n - 1, 40 * avg_deg)   # a few very long rows
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
+    vals = rng.uniform(0.01, 0.4, len(indices)).astype(np.float32)
+    return indptr, indices, vals
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_spmm_vs_oracle_random(pkg, oracle, d):
+    rng = np.random.Generator(np.random.PCG64(d))
+    indptr, indices, vals = _random_graph(rng, 3001, 9, heavy=3)
+    X = rng.normal(0, 0.1, (3001, d)).astype(np.float32)
+    ref = oracle.spmm(indptr, indices, vals, X)
+    got = _spmm(pkg, indptr, indices, vals, X)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+    # bf16 storage of the gathered table and of the output: fp32 accumulate
+    Xb = torch.from_numpy(X).to(torch.bfloat16).float().numpy()
+    refb = oracle.spmm(indptr, indices, vals, Xb)
+    gotb = _spmm(pkg, indptr, indices, vals, X, x_dtype=1, y_dtype=0)
+    np.testing.assert_allclose(gotb, refb, rtol=2e-5, atol=1e-6)
+    gotbb = _spmm(pkg, indptr, indices, vals, X, x_dtype=1, y_dtype=1)
+    np.testing.assert_allclose(gotbb, refb, rtol=1e-2, atol=1e-4)
+
+
+def test_spmm_edge_cases(pkg, oracle):
+    # single row, empty matrix rows only, one neighbour
+    X = np.arange(2 * 64, dtype=np.float32).reshape(2, 64)
+    got = _spmm(pkg, np.array([0, 0, 0]), np.zeros(0, np.int32), np.zeros(0, np.float32), X)
+    assert np.array_equal(got, np.zeros_like(X))
+    got = _spmm(pkg, np.array([0, 1, 1]), np.array([1], np.int32), np.array([0.5], np.float32), X)
+    assert np.array_equal(got[0], 0.5 * X[1]) and np.all(got[1] == 0)
+    L = pkg._lib
+    assert L.load().lgcn_spmm_csr(None, None, None, 3, None, 0, None, 0, 64, None) != 0
+    assert b"null" in L.load().lgcn_last_error()
+    x = torch.zeros(4, 48, device=DEV)
+    ip = torch.zeros(5, dtype=torch.int32, device=DEV)
+    assert L.load().lgcn_spmm_csr(L.tp(ip), L.tp(ip), L.tp(x), 4, L.tp(x), 0, L.tp(x), 0, 48, None) == 3
+
+
+def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None):
+    d = os.path.join(str(tmp_path), g.name + act_dtype)
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(g.dir, f), os.path.join(d, f))
+    w = pkg.world
+    w.configure([])
+    w.dataset = g.name
+    w.config.update({'lightGCN_n_layers': K or g.K, 'latent_dim_rec': g.d, 'bpr_batch_size': B or g.B,
+                     'act_dtype': act_dtype, 'decay': g.meta["decay"], 'lr': g.meta["lr"]})
+    w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    pkg.sampling.seed(w.seed)
+    pkg.utils.set_seed(w.seed)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    return ds, m
+
+
+def test_computer_vs_golden_and_oracle(pkg, oracle, tiny, lastfm, tmp_path):
+    for g in (tiny, lastfm):
+        ds, m = _make_model(pkg, g, tmp_path)
+        assert np.array_equal(m._table.cpu().numpy(), g.e0())                    # seed-2020 init, bit-exact
+        with torch.no_grad():
+            au, ai = m.computer()
+        got = torch.cat([au, ai]).cpu().numpy()
+        ref = oracle.propagate(g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"], g.e0(), g.K)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-7)
+        gold = np.concatenate([g.z["computer_users"], g.z["computer_items"]], 0)
+        np.testing.assert_allclose(np.concatenate([got[:g.n_users][::g.stride], got[g.n_users:][::g.stride]]),
+                                   gold, rtol=2e-5, atol=2e-7)
+
+
+def test_unfused_bpr_loss_autograd_vs_golden(pkg, tiny, tmp_path):
+    """model.bpr_loss + loss.backward() (the reference's own stageOne recipe) through the
+    custom autograd Function: loss, reg and both parameter gradients."""
+    g = tiny
+    ds, m = _make_model(pkg, g, tmp_path)
+    m.train()
+    loss, reg = m.bpr_loss(_dev(g.z["b_users"]), _dev(g.z["b_pos"]), _dev(g.z["b_neg"]))
+    assert abs(float(loss) - g.meta["b_loss"]) < 2e-6 and abs(float(reg) - g.meta["b_reg"]) < 2e-6
+    (loss + reg * g.meta["decay"]).backward()
+    np.testing.assert_allclose(m.embedding_user.weight.grad.cpu().numpy(), g.z["b_grad_user"], rtol=2e-4, atol=2e-9)
+    np.testing.assert_allclose(m.embedding_item.weight.grad.cpu().numpy(), g.z["b_grad_item"], rtol=2e-4, atol=2e-9)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+def test_fused_step_vs_oracle(pkg, oracle, tiny, tmp_path, K):
+    """One fused stageOne vs the oracle's stageOne for every layer count (K=1 exercises the
+    sparse-input + Adam kernel, K=2 the single-buffer chain, K=4 the ping-pong)."""
+    g = tiny
+    ds, m = _make_model(pkg, g, tmp_path, K=K)
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    tr = oracle.Trainer(g.n_users, *A, g.e0(), K, g.meta["decay"], g.meta["lr"])
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    rng = np.random.Generator(np.random.PCG64(K))
+    for step in range(3):
+        nb = [64, 17, 1][step]
+        u = rng.integers(0, g.n_users, nb); p = rng.integers(0, g.m_items, nb); n = rng.integers(0, g.m_items, nb)
+        if step == 0:
+            u[:8] = u[0]; p[:8] = p[0]; n[8:12] = p[0]          # duplicates / pos-neg collisions
+        l_ref = tr.stageOne(u, p, n)
+        l_got = bpr.stageOne(_dev(u), _dev(p), _dev(n))
+        assert abs(l_got - l_ref) < 3e-6, (step, l_got, l_ref)
+        np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=3e-6)
+    st = m._dev
+    np.testing.assert_allclose(st['adam_m'].cpu().numpy(), tr.m, rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(st['adam_v'].cpu().numpy(), tr.v, rtol=2e-3, atol=1e-13)
+    # workspace is clean again after the step
+    assert int(st['G64'].abs().sum()) == 0 and float(st['Gs'].abs().sum()) == 0 and int(st['bitmap'].abs().sum()) == 0
+    m.check_device_errors()
+
+
+def test_epochs_tiny_vs_golden(pkg, tiny, tmp_path):
+    """Two epochs driven exactly like main.py:215-225 through the product's own sampler,
+    shuffle and fused step: triplets bit-exact, losses / parameters / Adam state vs the
+    reference's."""
+    g = tiny
+    ds, m = _make_model(pkg, g, tmp_path)
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    for e in (1, 2):
+        S = pkg.utils.UniformSample_original(ds)
+        assert np.array_equal(S, g.z[f"S_epoch{e}"])
+        users, pos, neg = (torch.tensor(S[:, c], dtype=torch.long, device=DEV) for c in range(3))
+        users, pos, neg = pkg.utils.shuffle(users, pos, neg)
+        assert np.array_equal(users.cpu().numpy(), g.z[f"shuf_users_epoch{e}"])
+        assert np.array_equal(neg.cpu().numpy(), g.z[f"shuf_neg_epoch{e}"])
+        losses = [bpr.stageOne(bu, bp, bn) for (bu, bp, bn) in pkg.utils.minibatch(users, pos, neg, batch_size=g.B)]
+        np.testing.assert_allclose(losses, g.z[f"losses_epoch{e}"], rtol=0, atol=3e-6)
+        P = np.concatenate([g.z[f"P_user_epoch{e}"], g.z[f"P_item_epoch{e}"]], 0)
+        np.testing.assert_allclose(m._table.cpu().numpy(), P, rtol=0, atol=6e-6)
+    sd = bpr.opt.state_dict()
+    assert int(sd['state'][0]['step']) == 2 * g.meta["adam_step_epoch1"]
+    assert sd['param_groups'][0]['lr'] == g.meta["lr"]
+
+
+def test_procedure_epoch_lastfm_vs_golden(pkg, lastfm, tmp_path):
+    """Config C1 (LastFM, K=2, python-mode sampler): Procedure.BPR_train_original + Test vs the
+    reference's per-step losses and Recall/NDCG/Precision@20 before and after one epoch."""
+    g = lastfm
+    ds, m = _make_model(pkg, g, tmp_path)
+    pkg.world.tensorboard = 0
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    r0 = pkg.Procedure.Test(ds, m, 0)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(r0[k][0] - g.meta["test_epoch0"][k][0]) < 1e-7, k
+    # same epoch twice: once step by step (losses), once through the epoch procedure
+    users, pos, neg = pkg.Procedure.sample_epoch_to_device(ds, DEV)
+    assert np.array_equal(users.cpu().numpy(), g.z["shuf_users_epoch1"])
+    losses = m.fused_epoch(users, pos, neg, g.B)[:, 0].cpu().numpy()
+    np.testing.assert_allclose(losses, g.z["losses_epoch1"], rtol=0, atol=5e-6)
+    r1 = pkg.Procedure.Test(ds, m, 1)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(r1[k][0] - g.meta["test_epoch1"][k][0]) < 1e-4, (k, r1[k], g.meta["test_epoch1"][k])
+    out = pkg.Procedure.BPR_train_original(ds, m, bpr, 2)
+    assert out.startswith("loss0.") and "|Sample:" in out
+    r2 = pkg.Procedure.Test(ds, m, 2)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(r2[k][0] - g.meta["test_epoch2"][k][0]) < 1e-4, (k, r2[k], g.meta["test_epoch2"][k])
+    assert os.path.exists(os.path.join(pkg.world.config['checkpoint_dir'], 'train_epoch_metrics.csv'))
+
+
+def test_bitwise_reproducible_and_dp_split(pkg, tiny, tmp_path):
+    """(a) two runs of the same steps give identical bits (fixed-point gradient reduction);
+    (b) the data-parallel split (part1 per rank -> concatenated blocks -> part2) equals the
+    single-GPU step bit for bit, for world = 2 and 3 with a ragged last shard."""
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(1))
+    batches = [(rng.integers(0, g.n_users, b), rng.integers(0, g.m_items, b), rng.integers(0, g.m_items, b))
+               for b in (64, 64, 37)]
+
+    def run(world):
+        ds, m = _make_model(pkg, g, tmp_path)
+        L, lib = pkg._lib, pkg._lib.load()
+        losses = []
+        for (u, p, n) in batches:
+            u, p, n = (_dev(x, torch.int32) for x in (u, p, n))
+            B = len(u)
+            if world == 1:
+                losses.append(m.fused_step(u, p, n).cpu().numpy())
+                continue
+            st = m._state(max_batch=64, need_ctx=True, dp_world=world)
+            nblk = pkg.parallel.block_numel(B, world, g.d)
+            blocks = []
+            for r in range(world):
+                L.check(lib.lgcn_train_step_dp_part1(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, r,
+                                                     L.current_stream()), "part1")
+                blocks.append(st['contrib'][:nblk].clone())
+            gathered = torch.cat(blocks)
+            out = torch.empty(3, device=DEV)
+            L.check(lib.lgcn_train_step_dp_part2(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, L.tp(gathered),
+                                                 L.tp(out), L.current_stream()), "part2")
+            losses.append(out.cpu().numpy())
+        return m._table.cpu().numpy().copy(), np.array(losses)
+
+    p1, l1 = run(1)
+    p1b, l1b = run(1)
+    assert np.array_equal(p1.view(np.uint32), p1b.view(np.uint32)) and np.array_equal(l1, l1b)
+    for world in (2, 3):
+        pw, lw = run(world)
+        assert np.array_equal(p1.view(np.uint32), pw.view(np.uint32)), world
+        np.testing.assert_allclose(lw, l1, rtol=0, atol=1e-6)
+
+
+def test_out_of_range_ids_are_flagged_not_faulting(pkg, tiny, tmp_path):
+    ds, m = _make_model(pkg, tiny, tmp_path)
+    before = m._table.clone()
+    m.fused_step(_dev(np.array([0, tiny.n_users + 5]), torch.int32), _dev(np.array([1, 2]), torch.int32),
+                 _dev(np.array([tiny.m_items, 3]), torch.int32))
+    with pytest.raises(pkg._lib.LgcnError, match="out-of-range"):
+        m.check_device_errors()
+    m.check_device_errors()          # flag is cleared
+    assert torch.isfinite(m._table).all() and before.shape == m._table.shape
+
+
+def test_apply_perm_bit_exact(pkg):
+    rng = np.random.Generator(np.random.PCG64(3))
+    T = 100003
+    S = rng.integers(0, 1 << 30, (T, 3)).astype(np.int32)
+    perm = rng.permutation(T).astype(np.int64)
+    L = pkg._lib
+    Sd, pd = _dev(S), _dev(perm)
+    u, p, n = (torch.empty(T, dtype=torch.int32, device=DEV) for _ in range(3))
+    L.check(L.load().lgcn_apply_perm(L.tp(Sd), 3, L.tp(pd), T, L.tp(u), L.tp(p), L.tp(n), L.current_stream()), "perm")
+    assert np.array_equal(u.cpu().numpy(), S[perm, 0]) and np.array_equal(n.cpu().numpy(), S[perm, 2])
+
+
+def test_bf16_activation_mode(pkg, oracle, tiny, tmp_path):
+    g = tiny
+    ds, m = _make_model(pkg, g, tmp_path, act_dtype="bf16")
+    with torch.no_grad():
+        au, ai = m.computer()
+    ref = oracle.propagate(g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"], g.e0(), g.K)
+    np.testing.assert_allclose(torch.cat([au, ai]).cpu().numpy(), ref, rtol=2e-2, atol=2e-4)
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    l = bpr.stageOne(_dev(g.z["b_users"]), _dev(g.z["b_pos"]), _dev(g.z["b_neg"]))
+    assert abs(l - g.meta["b_total"]) < 5e-4
+
+
+def test_gowalla_full_size_properties_and_known_answer(pkg, oracle, tmp_path):
+    """BASELINE configs[1] size (N = 70 839, nnz = 1 620 256): adjacency hashes, seed-2020 init
+    hash, the reference's OWN epoch-0 known answer (tfevents 0.000188/0.000537/0.000408),
+    first step losses, and size-independent properties of the SpMM (linearity, symmetry
+    <y, A x> = <A y, x>, A 1 = rowsum) on the real graph."""
+    npz = os.path.join(GOLDEN, "gowalla", "gowalla.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "gowalla", "golden_long.json")))
+    zl = np.load(os.path.join(GOLDEN, "gowalla", "golden_long.npz"))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import materialize_gowalla
+    d = materialize_gowalla(npz, os.path.join(str(tmp_path), "gowalla"))
+    w = pkg.world
+    w.configure([]); w.dataset = "gowalla"; w.tensorboard = 0
+    w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    adj = ds.getSparseGraphCSR()
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(adj.indptr) == meta["adj_sha256"]["indptr"] and sha(adj.indices) == meta["adj_sha256"]["indices"]
+    assert sha(adj.data) == meta["adj_sha256"]["data"]                     # A_hat bit-exact at full size
+    pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    assert sha(m.embedding_user.weight.detach().cpu().numpy()) == meta["E0_sha256"]["user"]
+    with torch.no_grad():
+        au, ai = m.computer()
+    np.testing.assert_allclose(au[:8].cpu().numpy(), zl["computer_users_head"], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(ai[:8].cpu().numpy(), zl["computer_items_head"], rtol=2e-5, atol=2e-7)
+    assert abs(float(au.double().sum()) - meta["computer_sum"][0]) < 1e-2
+    r0 = pkg.Procedure.Test(ds, m, 0)
+    for k in ("precision", "recall", "ndcg"):
+        assert abs(r0[k][0] - meta["test_epoch0"][k][0]) < 1e-8, (k, r0[k])
+    # properties
+    N = ds.n_users + ds.m_items
+    gen = torch.Generator(device="cpu"); gen.manual_seed(5)
+    x = torch.randn(N, 64, generator=gen).to(DEV); y = torch.randn(N, 64, generator=gen).to(DEV)
+    Ax, Ay = m._spmm(x), m._spmm(y)
+    lin = m._spmm(2.0 * x - 0.5 * y)
+    assert torch.allclose(lin, 2.0 * Ax - 0.5 * Ay, rtol=1e-4, atol=1e-5)
+    assert abs(float((y.double() * Ax.double()).sum() - (Ay.double() * x.double()).sum())) < 1e-6 * N
+    ones = m._spmm(torch.ones(N, 64, device=DEV))
+    rs = np.asarray(adj.sum(axis=1)).ravel()
+    np.testing.assert_allclose(ones[:, 0].cpu().numpy(), rs, rtol=1e-5, atol=1e-6)
+    # first steps of epoch 1 vs the reference's recorded per-step losses
+    bpr = pkg.utils.BPRLoss(m, w.config)
+    users, pos, neg = pkg.Procedure.sample_epoch_to_device(ds, DEV)
+    assert users[:5].cpu().tolist() == meta["trajectory"][0]["shuf_users_head"]
+    losses = m.fused_epoch(users[:2048 * 20], pos[:2048 * 20], neg[:2048 * 20], 2048)[:, 0].cpu().numpy()
+    np.testing.assert_allclose(losses, zl["losses_epoch1"][:20], rtol=0, atol=5e-6)
+    m.check_device_errors()

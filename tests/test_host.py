@@ -1,0 +1,239 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every
+symbol include/lgcn_hip.h declares, the native samplers / shuffle / graph builder are
+bit-exact against the golden fixtures, the oracle and oracle/_ref, and the config surface
+matches the reference's flags.  No device compute is launched here."""
+import hashlib
+import importlib
+import json
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, PKG_NAME
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(REPO, "include", "lgcn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lgcn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = pkg._lib.load()
+    assert set(pkg._lib.SIGNATURES) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lgcn_abi_version() == 1
+    assert lib.lgcn_device_available() in (0, 1)
+
+
+def test_glibc_stream_and_randint(pkg):
+    s = pkg.sampling
+    s.seed(2020)
+    assert [s.randint(1000) for _ in range(5)] == [917, 315, 409, 907, 967]
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 2020, 0xFFFFFFFF, 0):
+        libc.srand(ctypes.c_uint(seed)); s.seed(seed)
+        assert [libc.rand() % 1000003 for _ in range(3000)] == [s.randint(1000003) for _ in range(3000)]
+
+
+def _load(pkg, g, tmp_path):
+    d = os.path.join(str(tmp_path), g.name)
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(g.dir, f), os.path.join(d, f))
+    pkg.world.dataset = g.name
+    return pkg.dataloader.Loader(pkg.world.config, path=d)
+
+
+def test_loader_and_graph_bit_exact(pkg, tiny, lastfm, tmp_path):
+    for g in (tiny, lastfm):
+        ds = _load(pkg, g, tmp_path)
+        assert (ds.n_users, ds.m_items, ds.trainDataSize) == (g.n_users, g.m_items, g.meta["trainDataSize"])
+        adj = ds.getSparseGraphCSR()
+        assert adj.indptr.dtype == np.int32 and adj.indices.dtype == np.int32 and adj.data.dtype == np.float32
+        assert np.array_equal(adj.indptr, g.z["adj_indptr"])
+        assert np.array_equal(adj.indices, g.z["adj_indices"])
+        assert np.array_equal(adj.data.view(np.uint32), g.z["adj_data"].view(np.uint32))
+        assert os.path.exists(os.path.join(ds.path, "s_pre_adj_mat.npz"))      # same cache file as the reference
+        # reload goes through the cache and gives the same matrix
+        ds2 = pkg.dataloader.Loader(pkg.world.config, path=ds.path)
+        adj2 = ds2.getSparseGraphCSR()
+        assert np.array_equal(adj2.data.view(np.uint32), adj.data.view(np.uint32))
+        coo = ds2.getSparseGraph()
+        assert coo.is_sparse and coo.shape == (g.n_users + g.m_items,) * 2 and coo._nnz() == len(adj.data)
+        assert all(np.all(np.diff(p) > 0) for p in ds.allPos if len(p) > 1)
+        td = ds.testDict
+        assert sum(len(v) for v in td.values()) == len(g.test_user)
+
+
+def test_sampler_cpp_matches_golden(pkg, tiny, tmp_path):
+    ds = _load(pkg, tiny, tmp_path)
+    pkg.sampling.seed(2020)
+    for e in (1, 2):
+        S = pkg.sampling.sample_negative(ds.n_users, ds.m_items, ds.trainDataSize, ds.allPos, 1)
+        assert S.dtype == np.int32 and np.array_equal(S, tiny.z[f"S_epoch{e}"])
+    # zero-copy CSR overload gives the same stream
+    pkg.sampling.seed(2020)
+    S = pkg.sampling.sample_negative(ds.n_users, ds.m_items, ds.trainDataSize, ds.pos_csr(), 1)
+    assert np.array_equal(S, tiny.z["S_epoch1"])
+
+
+def test_sampler_python_and_shuffle_match_golden(pkg, tiny, lastfm, tmp_path):
+    z = np.load(os.path.join(tiny.dir, "golden_python_sampler.npz"))
+    ds = _load(pkg, tiny, tmp_path)
+    pkg.utils.set_seed(2020)
+    S1 = pkg.utils.UniformSample_original_python(ds)
+    perm = pkg.utils.shuffle_indices(len(S1))
+    S2 = pkg.utils.UniformSample_original_python(ds)
+    assert S1.dtype == np.int64 and np.array_equal(S1, z["S_python_epoch1"])
+    assert np.array_equal(perm, z["perm_after_epoch1"]) and np.array_equal(S2, z["S_python_epoch2"])
+    ds = _load(pkg, lastfm, tmp_path)
+    assert pkg.utils.sampler_mode(ds) == "python"          # 14 users without positives
+    pkg.utils.set_seed(2020)
+    S = pkg.utils.UniformSample_original(ds)
+    assert sha(S) == lastfm.meta["S_epoch1_sha256"]
+    (su,), idx = pkg.utils.shuffle(S[:, 0], indices=True)
+    assert np.array_equal(su, lastfm.z["shuf_users_epoch1"])
+    # native stream == numpy's own legacy stream
+    np.random.seed(77); pkg._lib.load().lgcn_np_seed(77)
+    ref = np.arange(12345); np.random.shuffle(ref)
+    assert np.array_equal(ref, pkg.utils.shuffle_indices(12345))
+
+
+def test_sampler_rejects_user_without_positives(pkg, lastfm, tmp_path):
+    ds = _load(pkg, lastfm, tmp_path)
+    with pytest.raises(pkg._lib.LgcnError, match="no training positives"):
+        pkg.sampling.sample_negative(ds.n_users, ds.m_items, ds.trainDataSize, ds.pos_csr(), 1)
+
+
+def test_sampler_vs_compiled_reference_and_oracle(pkg, oracle):
+    ref_dir = os.path.join(REPO, "oracle", "_ref")
+    have_ref = os.path.isdir(ref_dir) and any(f.startswith("sampling") and f.endswith(".so") for f in os.listdir(ref_dir))
+    if have_ref:
+        sys.path.insert(0, ref_dir)
+        ref = importlib.import_module("sampling")
+    rng = np.random.Generator(np.random.PCG64(11))
+    n_users, m_items = 257, 403
+    rows = [np.sort(rng.choice(m_items, size=int(rng.integers(1, 90)), replace=False)).astype(np.int32)
+            for _ in range(n_users)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows)
+    train_num = int(indptr[-1])
+    for seed in (2020, 3):
+        pkg.sampling.seed(seed); oracle.srand(seed)
+        if have_ref:
+            ref.seed(seed)
+        for neg in (1, 2):
+            a = pkg.sampling.sample_negative(n_users, m_items, train_num, rows, neg)
+            b = oracle.sample_negative(n_users, m_items, train_num, indptr, indices, neg)
+            assert np.array_equal(a, b)
+            if have_ref:
+                c = ref.sample_negative(n_users, m_items, train_num, rows, neg)
+                assert c.dtype == a.dtype and c.shape == a.shape and np.array_equal(a, c)
+        us = rng.integers(0, n_users, 50).astype(np.int32)
+        a = pkg.sampling.sample_negative_ByUser(us, m_items, rows, 2)
+        assert np.array_equal(a, oracle.sample_negative_by_user(us, m_items, indptr, indices, 2))
+        if have_ref:
+            assert np.array_equal(a, ref.sample_negative_ByUser(us.tolist(), m_items, rows, 2))
+
+
+def test_gowalla_sampler_hashes(pkg):
+    """Full-size integer parity: 806 166 triplets per epoch, two epochs of the glibc stream,
+    the python-mode epoch and the 806 166-element shuffle, against hashes captured from the
+    reference on the reconstructed Gowalla graph."""
+    npz = os.path.join(GOLDEN, "gowalla", "gowalla.npz")
+    if not os.path.exists(npz):
+        pytest.skip("gowalla.npz fixture not generated")
+    meta = json.load(open(os.path.join(GOLDEN, "gowalla", "golden_samplers.json")))
+    z = np.load(npz)
+    lib = pkg._lib.load()
+    n_users, m_items = 29858, 40981
+    tu = np.repeat(z["train_users"].astype(np.int64), np.diff(z["train_ptr"]))
+    ti = z["train_items"].astype(np.int64)
+    indptr = np.zeros(n_users + 1, np.int64); nnz = np.zeros(1, np.int64)
+    indices = np.empty(len(ti), np.int32); vals = np.empty(len(ti), np.float32)
+    assert lib.lgcn_build_user_item_csr(n_users, m_items, len(ti), pkg._lib.npp(tu), pkg._lib.npp(ti),
+                                        pkg._lib.npp(indptr), pkg._lib.npp(indices), pkg._lib.npp(vals),
+                                        pkg._lib.npp(nnz)) == 0
+    assert int(nnz[0]) == 810128
+    pkg.sampling.seed(2020)
+    for e in (1, 2):
+        S = pkg.sampling.sample_negative(n_users, m_items, 810128, (indptr, indices), 1)
+        assert S.shape == (806166, 3) and sha(S) == meta[f"cpp_epoch{e}"]["sha256"]
+    pkg._lib.load().lgcn_np_seed(2020)
+    perm = pkg.utils.shuffle_indices(806166)
+    assert perm[:5].tolist() == meta["shuffle_806166_head"] and sha(perm) == meta["shuffle_806166_sha256"]
+    pkg._lib.load().lgcn_np_seed(2020)
+    S = np.empty((810128, 3), np.int64)
+    rows = lib.lgcn_sample_python(n_users, m_items, 810128, pkg._lib.npp(indptr), pkg._lib.npp(indices), pkg._lib.npp(S))
+    assert rows == 810128 and sha(S) == meta["python_epoch1"]["sha256"]
+
+
+def test_config_surface_matches_reference_flags(pkg):
+    w = pkg.world
+    w.configure([])
+    expect = {'lr': 0.001, 'decay': 1e-4, 'lightGCN_n_layers': 3, 'latent_dim_rec': 64, 'bpr_batch_size': 2048,
+              'test_u_batch_size': 100, 'dropout': 0, 'keep_prob': 0.6, 'A_split': False, 'A_n_fold': 100,
+              'epochs': 1000, 'multicore': 0, 'pretrain': 0, 'seed': 2020, 'model': 'lgn', 'dataset': 'gowalla',
+              'exp_smooth_beta': 0.5, 'use_ppr_weights': False, 'ppr_weights_path': None, 'use_scheduler': False,
+              'sched_gamma': 0.5, 'sched_milestones': [120, 240, 360, 480], 'use_pop_gate': False,
+              'pop_hidden': 32, 'gate_hidden': 64, 'gate_entropy_coeff': 1e-4, 'pop_gate_temp': 1.0,
+              'use_item_item': False, 'i2i_path': None, 'i2i_alpha': 0.0, 'checkpoint_dir': './checkpoints'}
+    for k, v in expect.items():
+        assert w.config[k] == v, k
+    assert (w.seed, w.dataset, w.comment, w.tensorboard, w.LOAD, w.model_name, w.TRAIN_epochs, w.topks) == \
+        (2020, 'gowalla', 'lgn', 1, 0, 'lgn', 1000, [20])
+    w.configure(['--layer', '4', '--recdim', '128', '--bpr_batch', '8192', '--topks', '[20, 40]', '--A_split'])
+    assert w.config['lightGCN_n_layers'] == 4 and w.config['latent_dim_rec'] == 128 and w.topks == [20, 40]
+    assert w.config['A_split'] is True
+    w.configure([])
+
+
+def test_minibatch_and_timer(pkg):
+    u = pkg.utils
+    a = np.arange(10)
+    out = list(u.minibatch(a, a * 2, batch_size=4))
+    assert [len(x[0]) for x in out] == [4, 4, 2] and np.array_equal(out[2][1], [16, 18])
+    with u.timer(name="Sample"):
+        pass
+    assert u.timer.dict().startswith("|Sample:")
+    u.timer.zero()
+    assert u.timer.NAMED_TAPE["Sample"] == 0
+
+
+def test_compute_fails_loudly_without_gpu(pkg, tiny, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ds = _load(pkg, tiny, tmp_path)
+    pkg.world.config['lightGCN_n_layers'], pkg.world.config['latent_dim_rec'] = 3, 64
+    m = pkg.model.LightGCN(pkg.world.config, ds)
+    assert list(m.state_dict().keys()) == ['embedding_user.weight', 'embedding_item.weight']
+    with pytest.raises(pkg._lib.LgcnError):
+        m.computer()
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    with pytest.raises(pkg._lib.LgcnError):
+        bpr.stageOne(np.array([0]), np.array([1]), np.array([2]))
+
+
+def test_model_init_matches_reference_rng(pkg, tiny, tmp_path):
+    ds = _load(pkg, tiny, tmp_path)
+    pkg.world.config['lightGCN_n_layers'], pkg.world.config['latent_dim_rec'] = tiny.K, tiny.d
+    pkg.utils.set_seed(2020)
+    m = pkg.model.LightGCN(pkg.world.config, ds)
+    assert np.array_equal(m.embedding_user.weight.detach().numpy(), tiny.z["E0_user"])
+    assert np.array_equal(m.embedding_item.weight.detach().numpy(), tiny.z["E0_item"])
+    # one storage
+    assert m.embedding_item.weight.data_ptr() == m._table.data_ptr() + tiny.n_users * tiny.d * 4
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert m.embedding_user.weight.data_ptr() == m._table.data_ptr()
+    assert np.allclose(m._table[:tiny.n_users].numpy(), tiny.z["E0_user"] + 1)
