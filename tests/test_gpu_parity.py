@@ -32,6 +32,8 @@ def _dev(a, dtype=None):
 def _spmm(pkg, indptr, indices, vals, X, x_dtype=0, y_dtype=0):
     L = pkg._lib
     n, d = len(indptr) - 1, X.shape[1]
+    if len(indices) == 0:            # empty device tensors have a null data_ptr: keep one unused slot
+        indices, vals = np.zeros(1, np.int32), np.zeros(1, np.float32)
     ip, ix, vv = _dev(indptr.astype(np.int32)), _dev(indices.astype(np.int32)), _dev(vals.astype(np.float32))
     x = _dev(X.astype(np.float32))
     if x_dtype == 1:
