@@ -226,8 +226,7 @@ def main():
         stream = L.current_stream()
 
         def spmm_once():
-            L.check(lib.lgcn_spmm_csr(L.tp(st['indptr']), L.tp(st['indices']), L.tp(st['vals']), N, L.tp(x), adt,
-                                      L.tp(y), adt, d, stream), "spmm")
+            L.check(lib.lgcn_spmm_csr(st['graph'].handle, L.tp(x), adt, L.tp(y), adt, d, stream), "spmm")
         for _ in range(10):
             spmm_once()
         reps = 100

@@ -20,11 +20,10 @@ _vp = C.c_void_p
 class TrainConfig(C.Structure):
     """Mirror of lgcn_train_config (include/lgcn_hip.h)."""
     _fields_ = [
-        ("indptr", _vp), ("indices", _vp), ("vals", _vp),
-        ("N", C.c_int64), ("nnz", C.c_int64),
+        ("graph", _vp),
         ("n_users", C.c_int32), ("d", C.c_int32), ("K", C.c_int32), ("act_dtype", C.c_int32),
         ("E0", _vp), ("adam_m", _vp), ("adam_v", _vp),
-        ("act", _vp), ("G64", _vp), ("Gs", _vp), ("bitmap", _vp), ("terms", _vp), ("contrib", _vp),
+        ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("contrib", _vp),
         ("err", _vp), ("max_batch", C.c_int32),
         ("decay", C.c_float),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
@@ -47,8 +46,10 @@ SIGNATURES = {
     "lgcn_build_user_item_csr": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgcn_adj_rowsum": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "lgcn_build_norm_adj": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "lgcn_spmm_csr": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
-    "lgcn_propagate_mean": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp)]),
+    "lgcn_graph_destroy": (None, [_vp]),
+    "lgcn_spmm_csr": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "lgcn_propagate_mean": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "lgcn_apply_perm": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
     "lgcn_ctx_create": (C.c_int, [C.POINTER(TrainConfig), C.POINTER(_vp)]),
     "lgcn_ctx_destroy": (None, [_vp]),
@@ -75,7 +76,9 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB_PATH
-    if _build.is_stale():
+    if os.environ.get("LGCN_LIB_PATH"):
+        pass                                   # explicit tuning variant: use as is
+    elif _build.is_stale():
         if _build.find_hipcc() is not None:
             _build.build()
         elif not os.path.exists(path):
@@ -124,3 +127,48 @@ def require_gpu():
 def current_stream():
     import torch
     return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+class Graph:
+    """Owner of an lgcn_graph handle over device CSR tensors (kept alive here)."""
+
+    def __init__(self, indptr, indices, vals, d_max=256):
+        import torch
+        require_gpu()
+        self.indptr = indptr.to(torch.int32).contiguous()
+        self.indices = indices.to(torch.int32).contiguous()
+        self.vals = vals.to(torch.float32).contiguous()
+        if self.indices.numel() == 0:        # keep pointers non-null for an empty matrix
+            self.indices = torch.zeros(1, dtype=torch.int32, device=self.indptr.device)
+            self.vals = torch.zeros(1, dtype=torch.float32, device=self.indptr.device)
+            nnz = 0
+        else:
+            nnz = int(indices.numel())
+        self.n_rows = int(self.indptr.numel()) - 1
+        self.nnz = nnz
+        h = _vp()
+        check(load().lgcn_graph_create(tp(self.indptr), tp(self.indices), tp(self.vals), self.n_rows, nnz,
+                                       int(d_max), C.byref(h)), "lgcn_graph_create")
+        self.handle = h
+
+    def spmm(self, x, y_dtype=None):
+        import torch
+        x = x.contiguous()
+        xd = BF16 if x.dtype == torch.bfloat16 else F32
+        if xd == F32:
+            x = x.float()
+        yd = xd if y_dtype is None else y_dtype
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if yd == BF16 else torch.float32, device=x.device)
+        check(load().lgcn_spmm_csr(self.handle, tp(x), xd, tp(y), yd, int(x.shape[1]), current_stream()), "lgcn_spmm_csr")
+        return y
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().lgcn_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

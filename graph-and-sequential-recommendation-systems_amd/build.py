@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 SOURCES = [os.path.join(PKG_DIR, "csrc", "lgcn_device.hip"), os.path.join(PKG_DIR, "csrc", "lgcn_host.cpp")]
 HEADER = os.path.join(REPO_DIR, "include", "lgcn_hip.h")
-LIB_PATH = os.path.join(PKG_DIR, "liblgcn_hip.so")
+LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(PKG_DIR, "liblgcn_hip.so")   # env: pick a tuning variant
 
 
 def find_hipcc():
@@ -25,8 +25,11 @@ def is_stale():
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in SOURCES + [HEADER])
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source for gfx950 into liblgcn_hip.so.  Returns the path."""
+    global LIB_PATH
+    if out is not None:
+        LIB_PATH = out
     if not force and not is_stale():
         return LIB_PATH
     hipcc = find_hipcc()

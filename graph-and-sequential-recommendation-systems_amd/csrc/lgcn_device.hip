@@ -25,6 +25,7 @@
 #include <string.h>
 #include <math.h>
 #include <new>
+#include <vector>
 
 #include "lgcn_hip.h"
 
@@ -45,6 +46,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __bf16 bf16_t;
 
+#ifndef LGCN_GATHER_U
+#define LGCN_GATHER_U 8      /* row gathers in flight per lane */
+#endif
 #define FIXED_SCALE 1125899906842624.0   /* 2^50 */
 #define FIXED_INV   8.8817841970012523e-16 /* 2^-50 */
 
@@ -64,44 +68,131 @@ __device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
 }
 __device__ __forceinline__ bool bit_set(const uint32_t *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
+// fixed-point gradient row -> fp32 Gs row:  (float)(q * 2^-50) / (K+1)
+__device__ __forceinline__ f32x4 load4_fixed(const long long *p, float div) {
+    typedef __attribute__((ext_vector_type(2))) long long i64x2_;
+    const i64x2_ a = *reinterpret_cast<const i64x2_ *>(p), b = *reinterpret_cast<const i64x2_ *>(p + 2);
+    f32x4 r;
+    r.x = (float)((double)a.x * FIXED_INV) / div; r.y = (float)((double)a.y * FIXED_INV) / div;
+    r.z = (float)((double)b.x * FIXED_INV) / div; r.w = (float)((double)b.y * FIXED_INV) / div;
+    return r;
+}
+
+struct GatherSrc {           // what a row gather reads
+    const void *X;           // [N,D] of TI, or the fixed-point table when SPARSE
+    const uint32_t *bm;      // SPARSE: non-zero-row bitmap
+    float div;               // SPARSE: K+1
+};
+
+// Raw (unconverted) 4-column piece of a gathered row.  The conversion to fp32 is kept OUT
+// of the predicated load block: hipcc otherwise waits vmcnt(0) inside every block and the
+// U gathers serialise (measured: bf16 SpMM 2x slower than fp32).
+typedef __attribute__((ext_vector_type(2))) long long i64x2;
+struct fixed4 { i64x2 a, b; };
+template <typename TI, bool SPARSE> struct Raw;
+template <> struct Raw<float, false> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T zero() { return T{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        return *reinterpret_cast<const T *>((const float *)s.X + (int64_t)col * D + l * 4); }
+    static __device__ __forceinline__ f32x4 cvt(const T &r, float) { return r; }
+};
+template <> struct Raw<bf16_t, false> {
+    typedef bf16x4 T;
+    static __device__ __forceinline__ T zero() { return __builtin_convertvector(f32x4{0.f, 0.f, 0.f, 0.f}, T); }
+    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 4); }
+    static __device__ __forceinline__ f32x4 cvt(const T &r, float) { return __builtin_convertvector(r, f32x4); }
+};
+template <typename TI> struct Raw<TI, true> {
+    typedef fixed4 T;
+    static __device__ __forceinline__ T zero() { return T{i64x2{0, 0}, i64x2{0, 0}}; }
+    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        const long long *p = (const long long *)s.X + (int64_t)col * D + l * 4;
+        return T{*reinterpret_cast<const i64x2 *>(p), *reinterpret_cast<const i64x2 *>(p + 2)}; }
+    static __device__ __forceinline__ f32x4 cvt(const T &r, float div) {
+        f32x4 o;
+        o.x = (float)((double)r.a.x * FIXED_INV) / div; o.y = (float)((double)r.a.y * FIXED_INV) / div;
+        o.z = (float)((double)r.b.x * FIXED_INV) / div; o.w = (float)((double)r.b.y * FIXED_INV) / div;
+        return o; }
+};
+
 // ---------------------------------------------------------------------------------
-// One CSR row of  A_hat * X  computed by one wavefront.
-// Lane layout: LPR = D/4 lanes cover one embedding row with 4 columns each
-// (16 B fp32 / 8 B bf16 per lane); the wave's 64/LPR lane groups walk the row's
-// neighbours interleaved (group g takes nnz p = start+g, start+g+NPW, ...), U
-// neighbours deep, so every lane keeps U independent row loads in flight.  The
-// per-group partial sums are combined by xor-shuffles in a fixed order: the
-// result is deterministic and identical wherever this function is used (dense
-// SpMM, on-the-fly last layer in k_bpr).
+// One CSR row segment [start,end) of  A_hat * X  computed by one wavefront.
+//
+// The segment is walked in tiles of 64 non-zeros.  Per tile: every lane loads one
+// (col,val) pair -- one coalesced 256-byte read of each CSR stream -- and the tile is
+// staged in a wave-private LDS slot.  Then LPR = D/4 lanes cover one embedding row
+// with 4 columns each (16 B fp32 / 8 B bf16 per lane) and the wave's NPW = 64/LPR lane
+// groups take the staged neighbours interleaved, U deep, so every lane has up to U
+// independent row gathers in flight behind ONE index round trip.  SPARSE: only
+// neighbours whose row is flagged in the bitmap are staged (ballot + prefix-popcount
+// compaction), the rest cost no gather at all.
+// Partial sums are combined by xor-shuffles in a fixed order: deterministic, and
+// identical wherever this function is used.
 // ---------------------------------------------------------------------------------
+// stage one tile of n <= 64 (col,val) pairs held one per lane; returns the staged count
+template <bool SPARSE>
+__device__ __forceinline__ int tile_stage(int col, float val, int n, const GatherSrc &src, int lane, int2 *stage) {
+    if (!SPARSE) {
+        if (lane < n) stage[lane] = make_int2(col, __float_as_int(val));
+        return n;
+    }
+    const bool act = (lane < n) && bit_set(src.bm, col);
+    const unsigned long long mask = __ballot(act);
+    if (act) {
+        const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        stage[pos] = make_int2(col, __float_as_int(val));
+    }
+    return __popcll(mask);
+}
+
+// gather-accumulate the staged tile: group g takes entries g, g+NPW, ..., U in flight
+template <int D, typename TI, bool SPARSE>
+__device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
+    constexpr int LPR = D / 4, NPW = 64 / LPR, U = SPARSE ? 2 : LGCN_GATHER_U;   // few neighbours are active
+    typedef Raw<TI, SPARSE> R;
+    const int g = lane / LPR, l = lane % LPR;
+    for (int j = g; j < cnt; j += NPW * U) {
+        int2 cv[U]; typename R::T x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                        // all LDS reads first
+            // past-the-end slots re-read the tile's last entry with weight 0: every gather is
+            // unconditional (a predicated load makes hipcc wait for the previous one)
+            const int e = j + u * NPW;
+            cv[u] = stage[min(e, cnt - 1)];
+            if (e >= cnt) cv[u].y = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = R::load(src, cv[u].x, D, l);      // U gathers in flight
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(x[u], src.div);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ f32x4 reduce_groups(f32x4 acc) {
+#pragma unroll
+    for (int off = D / 4; off < 64; off <<= 1) acc += shfl_xor4(acc, off);
+    return acc;   // every lane group holds the full sum for its 4 columns
+}
+
 template <int D, typename TI, bool SPARSE>
 __device__ __forceinline__ f32x4 row_gather(const int32_t *__restrict__ indices,
                                             const float *__restrict__ vals, int start, int end,
-                                            const TI *__restrict__ X, const uint32_t *__restrict__ bm,
-                                            int lane) {
-    constexpr int LPR = D / 4, NPW = 64 / LPR, U = 4;
-    const int g = lane / LPR, l = lane % LPR;
+                                            const GatherSrc &src, int lane, int2 *stage) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int p = start + g;
-    for (; p + (U - 1) * NPW < end; p += U * NPW) {
-        int col[U]; float v[U]; f32x4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { col[u] = indices[p + u * NPW]; v[u] = vals[p + u * NPW]; }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (!SPARSE || bit_set(bm, col[u])) x[u] = load4(X + (int64_t)col[u] * D + l * 4);
-            else x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) acc += v[u] * x[u];
+    for (int base = start; base < end; base += 64) {
+        const int n = min(64, end - base);
+        int col = 0; float val = 0.f;
+        if (lane < n) { col = indices[base + lane]; val = vals[base + lane]; }
+        const int cnt = tile_stage<SPARSE>(col, val, n, src, lane, stage);
+        __builtin_amdgcn_wave_barrier();
+        tile_gather<D, TI, SPARSE>(stage, cnt, src, lane, acc);
+        __builtin_amdgcn_wave_barrier();
     }
-    for (; p < end; p += NPW) {
-        const int col = indices[p]; const float v = vals[p];
-        if (!SPARSE || bit_set(bm, col)) acc += v * load4(X + (int64_t)col * D + l * 4);
-    }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) acc += shfl_xor4(acc, off);
-    return acc;   // every lane group holds the full sum for its 4 columns
+    return reduce_groups<D>(acc);
 }
 
 // XCD-aware block->row-tile map: hardware deals workgroups round-robin over the 8
@@ -114,10 +205,32 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t bid, int64_t ntiles, in
     return (bid & 7) * per + (bid >> 3);   // may be >= ntiles: caller checks
 }
 
+// Rows with more than LONG_T (= one 64-entry tile) non-zeros leave the short-row path.  They
+// are cut into chunks of LONG_CH non-zeros that run as independent waves in front of the
+// grid (a single wave walking Gowalla's 1415-nnz row = 23 serial tiles was the critical
+// path = the entire 57 us of the un-split launch).  A row of one chunk is finished by its
+// wave; otherwise each chunk writes a partial row and takes a ticket, and the LAST arriver
+// sums the partials in chunk order (fixed order: bitwise reproducible whoever is last)
+// and runs the epilogue.
+#define LONG_T 64             /* rows with more non-zeros than one tile leave the short path */
+#ifndef SPMM_RW
+#define SPMM_RW 4            /* consecutive short rows per wave */
+#endif
+#define LONG_CH 128
+struct LongPlan {
+    const int32_t *long_row;      // [n_long] row ids with nnz > LONG_T
+    const int32_t *chunk_ptr;     // [n_long+1] prefix sum of chunks per long row
+    const int32_t *chunk_owner;   // [n_chunks] index into long_row
+    float *partials;              // [n_chunks, D]
+    int32_t *counters;            // [n_long] arrival tickets (zero between launches)
+    int32_t n_long, n_chunks;
+};
+
 struct SpmmArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
+    LongPlan lp;
     const void *X; void *Y;
-    const float *Gs; const uint32_t *bitmap;
+    const long long *G64; const uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
     float *P; float *M; float *V;
     int64_t n_rows;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
@@ -126,26 +239,13 @@ struct SpmmArgs {
 
 enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
 
-// Y = [Gs +] A_hat X   (4 rows per 256-thread workgroup, one wave per row)
-//   M_SPARSE: X is Gs (fp32) whose non-zero rows are flagged in `bitmap`
-//   M_ADDG  : epilogue adds Gs[row] where flagged           (Horner term)
-//   M_ADAM  : epilogue applies torch.optim.Adam to P/M/V with grad = result
-template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
-    constexpr int LPR = D / 4;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t ntiles = (a.n_rows + 3) >> 2;
-    const int64_t tile = tile_of_block(blockIdx.x, ntiles, a.remap);
-    if (tile >= ntiles) return;
-    const int64_t row = tile * 4 + wid;
-    if (row >= a.n_rows) return;
-    const int start = a.indptr[row], end = a.indptr[row + 1];
-    f32x4 acc = row_gather<D, TI, (MODE & M_SPARSE) != 0>(a.indices, a.vals, start, end,
-                                                         (const TI *)a.X, a.bitmap, lane);
-    if (lane >= LPR) return;
-    const int64_t off = row * D + lane * 4;
+//   M_ADDG  : add Gs[row] where flagged (Horner term)
+//   M_ADAM  : apply torch.optim.Adam to P/M/V with grad = result, else store to Y
+template <int D, typename TO, int MODE>
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, f32x4 acc) {
+    const int64_t off = row * D + l * 4;
     if ((MODE & M_ADDG) && bit_set(a.bitmap, (int)row)) {
-        f32x4 g = load4(a.Gs + off);
+        f32x4 g = load4_fixed(a.G64 + off, a.div);
         acc = g + acc;
     }
     if (MODE & M_ADAM) {
@@ -162,6 +262,97 @@ __global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
     }
 }
 
+// Y = [Gs +] A_hat X.  256-thread workgroups = 4 waves.  Blocks [0, chunk_blocks) run one
+// long-row chunk per wave, the remaining blocks one short row per wave.
+//   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
+template <int D, typename TI, typename TO, int MODE>
+__global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
+    constexpr int LPR = D / 4;
+    __shared__ int2 stage_lds[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    GatherSrc src;
+    src.X = (MODE & M_SPARSE) ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
+    const int chunk_blocks = (a.lp.n_chunks + 3) >> 2;
+    if ((int)blockIdx.x < chunk_blocks) {
+        // ---- one chunk of a long row ----
+        const int c = blockIdx.x * 4 + wid;
+        if (c >= a.lp.n_chunks) return;
+        const int o = a.lp.chunk_owner[c];
+        const int64_t row = a.lp.long_row[o];
+        const int first = a.lp.chunk_ptr[o], nch = a.lp.chunk_ptr[o + 1] - first;
+        const int rs = a.indptr[row], re = a.indptr[row + 1];
+        const int s0 = rs + (c - first) * LONG_CH, s1 = min(re, s0 + LONG_CH);
+        f32x4 acc = row_gather<D, TI, (MODE & M_SPARSE) != 0>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wid]);
+        if (nch == 1) {                                   // 65..128 non-zeros: one wave, no hand-off
+            if (lane < LPR) spmm_epilogue<D, TO, MODE>(a, row, lane, acc);
+            return;
+        }
+        // Publish the partial WRITE-THROUGH (sc1: two 8-byte agent-scope stores per lane, no release
+        // fence -- a release would write back this XCD's whole dirty L2, measured 2x on the launch),
+        // drain, take a ticket; the last arriver invalidates its L1 once and reads the partials
+        // (cdna guide G16, R1 form with a counter).
+        if (lane < LPR) {
+            typedef __attribute__((address_space(1))) unsigned long long gu64;
+            union { f32x4 v; unsigned long long q[2]; } pk; pk.v = acc;
+            gu64 *dst = (gu64 *)(a.lp.partials + (int64_t)c * D + lane * 4);
+            __hip_atomic_store(dst, pk.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, pk.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.lp.counters + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != nch - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.lp.counters + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        if (lane >= LPR) return;
+        f32x4 tot = load4(a.lp.partials + (int64_t)first * D + lane * 4);
+        for (int j = 1; j < nch; j++) tot += load4(a.lp.partials + (int64_t)(first + j) * D + lane * 4);
+        spmm_epilogue<D, TO, MODE>(a, row, lane, tot);
+        return;
+    }
+    // ---- SPMM_RW consecutive short rows per wave, walked one after the other; the first
+    //      index tile of row r+1 is in flight while row r gathers (hides two of the three
+    //      dependent round trips a 23-nnz row otherwise pays) ----
+    const int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
+    const int64_t tile = tile_of_block((int64_t)blockIdx.x - chunk_blocks, ntiles, a.remap);
+    if (tile >= ntiles) return;
+    const int64_t row0 = (tile * 4 + wid) * SPMM_RW;
+    if (row0 >= a.n_rows) return;
+    const int my_ip = a.indptr[min(row0 + lane, a.n_rows)];      // SPMM_RW+1 row pointers, one load
+    int ip[SPMM_RW + 1];
+#pragma unroll
+    for (int r = 0; r <= SPMM_RW; r++) ip[r] = __builtin_amdgcn_readlane(my_ip, r);
+    const bool split = a.lp.n_chunks > 0;
+    int col_n = 0; float val_n = 0.f;
+    {   // first tile of row 0
+        const int deg = ip[1] - ip[0];
+        if (!(split && deg > LONG_T) && lane < deg) { col_n = a.indices[ip[0] + lane]; val_n = a.vals[ip[0] + lane]; }
+    }
+#pragma unroll
+    for (int r = 0; r < SPMM_RW; r++) {
+        const int64_t row = row0 + r;
+        const int start = ip[r], end = ip[r + 1];
+        const bool live = (row < a.n_rows) && !(split && end - start > LONG_T);   // long rows: done by chunks
+        int cnt = 0;
+        if (live) cnt = tile_stage<(MODE & M_SPARSE) != 0>(col_n, val_n, min(64, end - start), src, lane, stage_lds[wid]);
+        __builtin_amdgcn_wave_barrier();
+        if (r + 1 < SPMM_RW && row + 1 < a.n_rows) {          // first tile of the next row: in flight during this row's gathers
+            const int ns = ip[r + 1], ndeg = ip[r + 2 <= SPMM_RW ? r + 2 : SPMM_RW] - ns;
+            if (!(split && ndeg > LONG_T) && lane < ndeg) { col_n = a.indices[ns + lane]; val_n = a.vals[ns + lane]; }
+        }
+        if (live) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            tile_gather<D, TI, (MODE & M_SPARSE) != 0>(stage_lds[wid], cnt, src, lane, acc);
+            __builtin_amdgcn_wave_barrier();
+            acc = reduce_groups<D>(acc);
+            if (lane < LPR) spmm_epilogue<D, TO, MODE>(a, row, lane, acc);
+        }
+    }
+}
+
 // out = (X_0 + X_1 + ... + X_{K-1} + A X_{K-1}) / (K+1)   -- last layer of computer()
 struct MeanArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -172,16 +363,19 @@ struct MeanArgs {
 template <int D, typename TI>
 __global__ void __launch_bounds__(256) k_spmm_mean(MeanArgs a) {
     constexpr int LPR = D / 4;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ int2 stage_lds[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ntiles = (a.n_rows + 3) >> 2;
     const int64_t tile = tile_of_block(blockIdx.x, ntiles, a.remap);
     if (tile >= ntiles) return;
     const int64_t row = tile * 4 + wid;
     if (row >= a.n_rows) return;
     const int start = a.indptr[row], end = a.indptr[row + 1];
+    GatherSrc src; src.bm = nullptr; src.div = 1.f;
     f32x4 xk;
-    if (a.K == 1) xk = row_gather<D, float, false>(a.indices, a.vals, start, end, a.X0, nullptr, lane);
-    else xk = row_gather<D, TI, false>(a.indices, a.vals, start, end, (const TI *)a.Xl[a.K - 1], nullptr, lane);
+    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, start, end, src, lane, stage_lds[wid]); }
+    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, start, end, src, lane, stage_lds[wid]); }
     if (lane >= LPR) return;
     const int64_t off = row * D + lane * 4;
     f32x4 s = load4(a.X0 + off);
@@ -192,12 +386,15 @@ __global__ void __launch_bounds__(256) k_spmm_mean(MeanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// Fused BPR: one 192-thread workgroup (3 waves) per triplet; wave c owns slot c
-// (0 user, 1 positive item, 2 negative item).
+// Fused BPR: one 768-thread workgroup per triplet = 3 slots (0 user, 1 positive item,
+// 2 negative item) x BW = 4 waves.  The 4 waves of a slot split the slot's CSR row into
+// contiguous quarters of 64-entry tiles (popular items have 1000+ neighbours: one wave
+// alone would be the critical path of the whole launch) and meet in LDS.
 //   1. e_c = mean_k X_k[row_c]; X_K[row_c] is computed on the fly from X_{K-1}
 //   2. x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ; r = |e_u|^2+|e_p|^2+|e_n|^2
 //   3. gradient row of slot c wrt the propagated table -> either
-//      fixed-point atomics into G64 (single GPU) or the exchange buffer (DP).
+//      fixed-point atomics into G64 + bitmap flag (single GPU) or the exchange
+//      buffer (data parallel).
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -209,6 +406,7 @@ struct BprArgs {
     float inv_B;          // 1 / global batch
     float lam;            // decay / global batch
     long long *G64;       // if non-null: atomics
+    uint32_t *bitmap;
     float *contrib;       // else: [3*shard*D | shard | shard]
     float *terms;         // single GPU: [2*B]  (loss terms, reg terms)
     int32_t *err;
@@ -220,11 +418,24 @@ __device__ __forceinline__ float sigmoid_neg_f(float x) {
     return x < 0.f ? 1.f / (1.f + z) : z / (1.f + z);
 }
 
+__device__ __forceinline__ void atomic_add_fixed4(long long *dst, f32x4 g) {
+    unsigned long long *d = (unsigned long long *)dst;
+    atomicAdd(d + 0, (unsigned long long)__double2ll_rn((double)g.x * FIXED_SCALE));
+    atomicAdd(d + 1, (unsigned long long)__double2ll_rn((double)g.y * FIXED_SCALE));
+    atomicAdd(d + 2, (unsigned long long)__double2ll_rn((double)g.z * FIXED_SCALE));
+    atomicAdd(d + 3, (unsigned long long)__double2ll_rn((double)g.w * FIXED_SCALE));
+}
+
+#define BPR_BW 4
 template <int D, typename TI>
-__global__ void __launch_bounds__(192) k_bpr(BprArgs a) {
+__global__ void __launch_bounds__(192 * BPR_BW) k_bpr(BprArgs a) {
     constexpr int LPR = D / 4;
-    __shared__ __attribute__((aligned(16))) float e_lds[3 * D];
-    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    __shared__ int2 stage_lds[3 * BPR_BW][64];
+    __shared__ __attribute__((aligned(16))) float part_lds[3 * BPR_BW][D];
+    __shared__ __attribute__((aligned(16))) float e_lds[3][D];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 .. 3*BW-1
+    const int c = wv / BPR_BW, q = wv % BPR_BW;
     const int b = blockIdx.x;
     int64_t row;
     bool bad = false;
@@ -233,24 +444,34 @@ __global__ void __launch_bounds__(192) k_bpr(BprArgs a) {
         int it = (c == 1) ? a.pos[b] : a.neg[b];
         bad = (it < 0 || (int64_t)it + a.n_users >= a.N); row = (int64_t)it + a.n_users;
     }
-    if (bad) { if (lane == 0) atomicExch(a.err, 1); row = 0; }
+    if (bad) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
     const int start = a.indptr[row], end = a.indptr[row + 1];
+    // quarter q of the row's 64-entry tiles
+    const int tiles = (end - start + 63) >> 6, per = (tiles + BPR_BW - 1) / BPR_BW;
+    const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
+    GatherSrc src; src.bm = nullptr; src.div = 1.f;
     f32x4 xk;
-    if (a.K == 1) xk = row_gather<D, float, false>(a.indices, a.vals, start, end, a.X0, nullptr, lane);
-    else xk = row_gather<D, TI, false>(a.indices, a.vals, start, end, (const TI *)a.Xl[a.K - 1], nullptr, lane);
-    if (lane < LPR) {
+    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wv]); }
+    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wv]); }
+    if (lane < LPR) store4(&part_lds[wv][lane * 4], xk);
+    __syncthreads();
+    if (q == 0 && lane < LPR) {
         const int64_t off = row * D + lane * 4;
         f32x4 s = load4(a.X0 + off);
         for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + off);
-        s += xk;
+        f32x4 t = load4(&part_lds[c * BPR_BW][lane * 4]);
+#pragma unroll
+        for (int w = 1; w < BPR_BW; w++) t += load4(&part_lds[c * BPR_BW + w][lane * 4]);
+        s += t;
         const float div = (float)(a.K + 1);
-        store4(&e_lds[c * D + lane * 4], s / div);
+        store4(&e_lds[c][lane * 4], s / div);
     }
     __syncthreads();
-    // every wave recomputes the (cheap) dots from LDS; lanes >= LPR contribute zeros
+    if (q != 0) return;
+    // wave (c,0) finishes slot c; the (cheap) dots are recomputed by each of the three
     f32x4 u4 = {0, 0, 0, 0}, p4 = u4, n4 = u4;
     if (lane < LPR) {
-        u4 = load4(&e_lds[lane * 4]); p4 = load4(&e_lds[D + lane * 4]); n4 = load4(&e_lds[2 * D + lane * 4]);
+        u4 = load4(&e_lds[0][lane * 4]); p4 = load4(&e_lds[1][lane * 4]); n4 = load4(&e_lds[2][lane * 4]);
     }
     float ps = u4.x * p4.x + u4.y * p4.y + u4.z * p4.z + u4.w * p4.w;
     float ns = u4.x * n4.x + u4.y * n4.y + u4.z * n4.z + u4.w * n4.w;
@@ -261,50 +482,51 @@ __global__ void __launch_bounds__(192) k_bpr(BprArgs a) {
     for (int off = 1; off < LPR; off <<= 1) {
         ps += __shfl_xor(ps, off); ns += __shfl_xor(ns, off); rr += __shfl_xor(rr, off);
     }
+    // an out-of-range id anywhere in the triplet voids the whole triplet
+    const bool tbad = (a.users[b] < 0 || a.users[b] >= a.n_users || a.pos[b] < 0 || (int64_t)a.pos[b] + a.n_users >= a.N ||
+                       a.neg[b] < 0 || (int64_t)a.neg[b] + a.n_users >= a.N);
     const float x = ps - ns;
-    const float gb = bad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
+    const float gb = tbad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
     if (c == 0 && lane == 0) {
         float *lt = a.G64 ? a.terms : a.contrib + (int64_t)3 * a.shard * D;
         const int stride = a.G64 ? a.B_local : a.shard;
-        lt[b] = bad ? 0.f : logsigmoid_f(x);
-        lt[stride + b] = bad ? 0.f : rr;
+        lt[b] = tbad ? 0.f : logsigmoid_f(x);
+        lt[stride + b] = tbad ? 0.f : rr;
     }
     if (lane < LPR) {
         f32x4 g;
         if (c == 0) g = gb * (p4 - n4) + a.lam * u4;
         else if (c == 1) g = gb * u4 + a.lam * p4;
         else g = (-gb) * u4 + a.lam * n4;
-        if (bad) g = f32x4{0, 0, 0, 0};
+        if (tbad) g = f32x4{0, 0, 0, 0};
         if (a.G64) {
-            unsigned long long *dst = (unsigned long long *)(a.G64 + row * D + lane * 4);
-            atomicAdd(dst + 0, (unsigned long long)__double2ll_rn((double)g.x * FIXED_SCALE));
-            atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)g.y * FIXED_SCALE));
-            atomicAdd(dst + 2, (unsigned long long)__double2ll_rn((double)g.z * FIXED_SCALE));
-            atomicAdd(dst + 3, (unsigned long long)__double2ll_rn((double)g.w * FIXED_SCALE));
+            if (!tbad) {
+                atomic_add_fixed4(a.G64 + row * D + lane * 4, g);
+                if (lane == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+            }
         } else {
             store4(a.contrib + ((int64_t)c * a.shard + b) * D + lane * 4, g);
         }
     }
 }
 
-// slot -> destination row of the global batch
+// slot -> destination row of the global batch (-1: the slot's triplet has a bad id)
 __device__ __forceinline__ int64_t slot_row(int c, int b, const int32_t *users, const int32_t *pos,
                                             const int32_t *neg, int32_t n_users, int64_t N) {
-    int64_t r;
-    if (c == 0) { int u = users[b]; r = (u < 0 || u >= n_users) ? -1 : u; }
-    else { int it = (c == 1) ? pos[b] : neg[b]; r = (it < 0 || (int64_t)it + n_users >= N) ? -1 : (int64_t)it + n_users; }
-    return r;
+    const int u = users[b], p = pos[b], n = neg[b];
+    if (u < 0 || u >= n_users || p < 0 || (int64_t)p + n_users >= N || n < 0 || (int64_t)n + n_users >= N) return -1;
+    return c == 0 ? (int64_t)u : (int64_t)(c == 1 ? p : n) + n_users;
 }
 
 struct SlotArgs {
     const int32_t *users; const int32_t *pos; const int32_t *neg;
     int32_t B; int32_t n_users; int64_t N;
-    long long *G64; float *Gs; uint32_t *bitmap;
+    long long *G64; uint32_t *bitmap;
     const float *gathered; int32_t shard; int32_t world;   // DP scatter
-    const float *terms; float *loss_out; float decay; int K;
+    const float *terms; float *loss_out; float decay;
 };
 
-// DP: order-independent scatter of every rank's gradient rows into G64
+// DP: order-independent scatter of every rank's gradient rows into G64 (+ row flags)
 template <int D>
 __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     constexpr int LPR = D / 4, SPB = 256 / LPR;
@@ -316,30 +538,23 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     const int r = b / a.shard, i = b % a.shard;
     const int64_t blk = (int64_t)3 * a.shard * D + 2 * a.shard;
     f32x4 g = load4(a.gathered + r * blk + ((int64_t)c * a.shard + i) * D + l * 4);
-    unsigned long long *dst = (unsigned long long *)(a.G64 + row * D + l * 4);
-    atomicAdd(dst + 0, (unsigned long long)__double2ll_rn((double)g.x * FIXED_SCALE));
-    atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)g.y * FIXED_SCALE));
-    atomicAdd(dst + 2, (unsigned long long)__double2ll_rn((double)g.z * FIXED_SCALE));
-    atomicAdd(dst + 3, (unsigned long long)__double2ll_rn((double)g.w * FIXED_SCALE));
+    atomic_add_fixed4(a.G64 + row * D + l * 4, g);
+    if (l == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
 }
 
-// Gs[row] = float(G64[row]) / (K+1), flag the row; block 0 also reduces the loss.
-// Slots that share a row write identical bits (benign).
+// End of step: zero what the step touched (G64 rows, bitmap words of the batch rows);
+// block 0 also reduces the per-triplet loss terms in a fixed order.
 template <int D>
-__global__ void __launch_bounds__(256) k_finalize(SlotArgs a) {
+__global__ void __launch_bounds__(256) k_finish(SlotArgs a) {
     constexpr int LPR = D / 4, SPB = 256 / LPR;
     const int s = blockIdx.x * SPB + threadIdx.x / LPR, l = threadIdx.x % LPR;
     if (s < 3 * a.B) {
         const int c = s / a.B, b = s % a.B;
         const int64_t row = slot_row(c, b, a.users, a.pos, a.neg, a.n_users, a.N);
         if (row >= 0) {
-            const long long *src = a.G64 + row * D + l * 4;
-            const float div = (float)(a.K + 1);
-            f32x4 g;
-            g.x = (float)((double)src[0] * FIXED_INV) / div; g.y = (float)((double)src[1] * FIXED_INV) / div;
-            g.z = (float)((double)src[2] * FIXED_INV) / div; g.w = (float)((double)src[3] * FIXED_INV) / div;
-            store4(a.Gs + row * D + l * 4, g);
-            if (l == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+                    i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + row * D + l * 4);
+            q[0] = i64x2{0, 0}; q[1] = i64x2{0, 0};
+            if (l == 0) a.bitmap[row >> 5] = 0u;
         }
     }
     if (blockIdx.x == 0) {   // deterministic loss reduction: fixed strided partials + LDS tree
@@ -368,21 +583,6 @@ __global__ void __launch_bounds__(256) k_finalize(SlotArgs a) {
     }
 }
 
-// zero what the step touched: G64 / Gs rows and bitmap words of the batch rows
-template <int D>
-__global__ void __launch_bounds__(256) k_cleanup(SlotArgs a) {
-    constexpr int LPR = D / 4, SPB = 256 / LPR;
-    const int s = blockIdx.x * SPB + threadIdx.x / LPR, l = threadIdx.x % LPR;
-    if (s >= 3 * a.B) return;
-    const int c = s / a.B, b = s % a.B;
-    const int64_t row = slot_row(c, b, a.users, a.pos, a.neg, a.n_users, a.N);
-    if (row < 0) return;
-    long long *q = a.G64 + row * D + l * 4;
-    q[0] = 0; q[1] = 0; q[2] = 0; q[3] = 0;
-    store4(a.Gs + row * D + l * 4, f32x4{0, 0, 0, 0});
-    if (l == 0) a.bitmap[row >> 5] = 0u;
-}
-
 __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, const int64_t *perm, int64_t T,
                                                    int32_t *users, int32_t *pos, int32_t *neg) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -402,12 +602,15 @@ static inline unsigned grid_rows(int64_t n_rows, int remap) {
 
 template <int D, typename TI, typename TO, int MODE>
 static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid_rows(a.n_rows, a.remap)), dim3(256), 0, st, a);
+    int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
+    if (a.remap) ntiles = ((ntiles + 7) / 8) * 8;
+    const unsigned grid = (unsigned)ntiles + (unsigned)((a.lp.n_chunks + 3) / 4);
+    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), 0, st, a);
 }
 
 template <int D, int MODE>
 static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, hipStream_t st) {
-    if (MODE & M_SPARSE) x_dtype = LGCN_F32;           // Gs is always fp32
+    if (MODE & M_SPARSE) x_dtype = LGCN_F32;           // source is the fixed-point table; TI unused
     if (MODE & M_ADAM) y_dtype = LGCN_F32;
     if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, st);
     else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, st);
@@ -448,13 +651,80 @@ extern "C" int lgcn_device_available(void) {
     return n > 0;
 }
 
-extern "C" int lgcn_spmm_csr(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t n_rows,
-                             const void *X, int x_dtype, void *Y, int y_dtype, int d, void *stream) {
-    if (!indptr || !indices || !vals || !X || !Y || n_rows < 0) { lgcn_set_error("lgcn_spmm_csr: null/invalid argument"); return 3; }
-    if (check_dtype(x_dtype) || check_dtype(y_dtype)) return 3;
-    if (n_rows == 0) return 0;
+// ---------------------------------------------------------------------------------
+// graph object: device CSR (borrowed) + the long-row plan and its scratch (owned)
+// ---------------------------------------------------------------------------------
+struct lgcn_graph {
+    const int32_t *indptr; const int32_t *indices; const float *vals;
+    int64_t n_rows, nnz;
+    int32_t d_max;
+    LongPlan lp;
+    void *owned;          // one device allocation holding plan arrays, partials and counters
+};
+
+extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
+                                 int64_t n_rows, int64_t nnz, int32_t d_max, lgcn_graph **out) {
+    if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
+        n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
+    if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
+    std::vector<int32_t> ip((size_t)n_rows + 1);
+    HIP_OK(hipMemcpy(ip.data(), indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost));
+    if (ip[0] != 0 || (int64_t)ip[(size_t)n_rows] != nnz) { lgcn_set_error("lgcn_graph_create: indptr does not match nnz"); return 3; }
+    std::vector<int32_t> long_row, chunk_ptr(1, 0), owner;
+    for (int64_t r = 0; r < n_rows; r++) {
+        const int64_t deg = (int64_t)ip[(size_t)r + 1] - ip[(size_t)r];
+        if (deg < 0) { lgcn_set_error("lgcn_graph_create: indptr not monotone"); return 3; }
+        if (deg > LONG_T) {
+            const int nch = (int)((deg + LONG_CH - 1) / LONG_CH);
+            for (int k = 0; k < nch; k++) owner.push_back((int32_t)long_row.size());
+            long_row.push_back((int32_t)r);
+            chunk_ptr.push_back(chunk_ptr.back() + nch);
+        }
+    }
+    lgcn_graph *g = new (std::nothrow) lgcn_graph;
+    if (!g) { lgcn_set_error("out of memory"); return 4; }
+    g->indptr = indptr; g->indices = indices; g->vals = vals; g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
+    g->owned = nullptr; g->lp = LongPlan{};
+    const size_t n_long = long_row.size(), n_chunks = owner.size();
+    if (n_long) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_row = 0, o_ptr = up(o_row + 4 * n_long), o_own = up(o_ptr + 4 * (n_long + 1)),
+                     o_cnt = up(o_own + 4 * n_chunks), o_par = up(o_cnt + 4 * n_long),
+                     total = o_par + n_chunks * (size_t)d_max * 4;
+        char *base = nullptr;
+        if (hipMalloc((void **)&base, total) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
+        g->owned = base;
+        HIP_OK(hipMemset(base, 0, total));
+        HIP_OK(hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice));
+        g->lp.long_row = (const int32_t *)(base + o_row); g->lp.chunk_ptr = (const int32_t *)(base + o_ptr);
+        g->lp.chunk_owner = (const int32_t *)(base + o_own); g->lp.counters = (int32_t *)(base + o_cnt);
+        g->lp.partials = (float *)(base + o_par);
+        g->lp.n_long = (int32_t)n_long; g->lp.n_chunks = (int32_t)n_chunks;
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
+    if (!g) return;
+    if (g->owned) (void)hipFree(g->owned);
+    delete g;
+}
+
+static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.indptr = indptr; a.indices = indices; a.vals = vals; a.X = X; a.Y = Y; a.n_rows = n_rows; a.remap = 0;
+    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.n_rows = g->n_rows; a.lp = g->lp;
+    return a;
+}
+
+extern "C" int lgcn_spmm_csr(const lgcn_graph *g, const void *X, int x_dtype, void *Y, int y_dtype, int d, void *stream) {
+    if (!g || !X || !Y) { lgcn_set_error("lgcn_spmm_csr: null/invalid argument"); return 3; }
+    if (check_dtype(x_dtype) || check_dtype(y_dtype)) return 3;
+    if (d > g->d_max) { lgcn_set_error("lgcn_spmm_csr: d exceeds the graph's d_max"); return 3; }
+    SpmmArgs a = graph_spmm(g);
+    a.X = X; a.Y = Y; a.remap = 1;
     int rc = launch_spmm<0>(a, d, x_dtype, y_dtype, (hipStream_t)stream);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
@@ -463,30 +733,29 @@ extern "C" int lgcn_spmm_csr(const int32_t *indptr, const int32_t *indices, cons
 
 static inline size_t esize(int dtype) { return dtype == LGCN_BF16 ? 2 : 4; }
 
-extern "C" int lgcn_propagate_mean(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t N,
-                                   const float *E0, int K, int d, int act_dtype, void *work, float *out,
-                                   void *stream) {
-    if (!indptr || !indices || !vals || !E0 || !out || K < 1 || K > LGCN_MAX_LAYERS || N <= 0) {
-        lgcn_set_error("lgcn_propagate_mean: invalid argument"); return 3;
-    }
+extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, int d, int act_dtype, void *work,
+                                   float *out, void *stream) {
+    if (!g || !E0 || !out || K < 1 || K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_propagate_mean: invalid argument"); return 3; }
     if (K > 1 && !work) { lgcn_set_error("lgcn_propagate_mean: workspace required for K > 1"); return 3; }
     if (check_dtype(act_dtype)) return 3;
+    if (d > g->d_max) { lgcn_set_error("lgcn_propagate_mean: d exceeds the graph's d_max"); return 3; }
     hipStream_t st = (hipStream_t)stream;
+    const int64_t N = g->n_rows;
     MeanArgs m{};
-    m.indptr = indptr; m.indices = indices; m.vals = vals; m.X0 = E0; m.K = K; m.out = out; m.n_rows = N; m.remap = 0;
+    m.indptr = g->indptr; m.indices = g->indices; m.vals = g->vals; m.X0 = E0; m.K = K; m.out = out; m.n_rows = N; m.remap = 1;
     const size_t stride = (size_t)N * d * esize(act_dtype);
     const void *prev = E0; int prev_dtype = LGCN_F32;
     for (int k = 1; k < K; k++) {
         void *y = (char *)work + (size_t)(k - 1) * stride;
-        SpmmArgs a{};
-        a.indptr = indptr; a.indices = indices; a.vals = vals; a.X = prev; a.Y = y; a.n_rows = N; a.remap = 0;
+        SpmmArgs a = graph_spmm(g);
+        a.X = prev; a.Y = y; a.remap = 1;
         int rc = launch_spmm<0>(a, d, prev_dtype, act_dtype, st);
         if (rc) return rc;
         m.Xl[k] = y; prev = y; prev_dtype = act_dtype;
     }
     DISPATCH_D(d, {
-        if (act_dtype == LGCN_F32) hipLaunchKernelGGL((k_spmm_mean<D, float>), dim3(grid_rows(N, 0)), dim3(256), 0, st, m);
-        else hipLaunchKernelGGL((k_spmm_mean<D, bf16_t>), dim3(grid_rows(N, 0)), dim3(256), 0, st, m);
+        if (act_dtype == LGCN_F32) hipLaunchKernelGGL((k_spmm_mean<D, float>), dim3(grid_rows(N, 1)), dim3(256), 0, st, m);
+        else hipLaunchKernelGGL((k_spmm_mean<D, bf16_t>), dim3(grid_rows(N, 1)), dim3(256), 0, st, m);
     });
     HIP_OK(hipGetLastError());
     return 0;
@@ -508,23 +777,25 @@ extern "C" int lgcn_apply_perm(const int32_t *S, int s_cols, const int64_t *perm
 struct lgcn_ctx {
     lgcn_train_config c;
     int64_t step;
+    int64_t N;
     void *act[LGCN_MAX_LAYERS];   // act[k] = X_k storage for k = 1..K-1 (also reused for H)
 };
 
 extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!cfg || !out) { lgcn_set_error("lgcn_ctx_create: null argument"); return 3; }
     const lgcn_train_config &c = *cfg;
-    if (!c.indptr || !c.indices || !c.vals || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 || !c.Gs ||
+    if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
         !c.bitmap || !c.terms || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
     if (c.K > 1 && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
     if (check_dtype(c.act_dtype)) return 3;
-    if (c.N <= 0 || c.n_users <= 0 || c.n_users >= c.N || c.max_batch <= 0) { lgcn_set_error("lgcn_ctx_create: bad sizes"); return 3; }
+    if (c.n_users <= 0 || c.n_users >= c.graph->n_rows || c.max_batch <= 0) { lgcn_set_error("lgcn_ctx_create: bad sizes"); return 3; }
+    if (c.d > c.graph->d_max) { lgcn_set_error("lgcn_ctx_create: d exceeds the graph's d_max"); return 3; }
     lgcn_ctx *x = new (std::nothrow) lgcn_ctx;
     if (!x) { lgcn_set_error("out of memory"); return 4; }
-    x->c = c; x->step = 0;
-    const size_t stride = (size_t)c.N * c.d * esize(c.act_dtype);
+    x->c = c; x->step = 0; x->N = c.graph->n_rows;
+    const size_t stride = (size_t)x->N * c.d * esize(c.act_dtype);
     for (int k = 0; k < LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
     for (int k = 1; k < c.K; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     *out = x;
@@ -536,9 +807,8 @@ extern "C" void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t s) { if (ctx) ctx->step
 extern "C" void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr) { if (ctx) ctx->c.lr = lr; }
 
 static SpmmArgs base_spmm(const lgcn_ctx *x) {
-    SpmmArgs a{};
-    a.indptr = x->c.indptr; a.indices = x->c.indices; a.vals = x->c.vals; a.n_rows = x->c.N;
-    a.Gs = x->c.Gs; a.bitmap = x->c.bitmap; a.remap = x->c.xcd_remap;
+    SpmmArgs a = graph_spmm(x->c.graph);
+    a.G64 = (const long long *)x->c.G64; a.bitmap = x->c.bitmap; a.div = (float)(x->c.K + 1); a.remap = x->c.xcd_remap;
     return a;
 }
 
@@ -560,39 +830,38 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
                    int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     BprArgs a{};
-    a.indptr = c.indptr; a.indices = c.indices; a.vals = c.vals; a.X0 = c.E0; a.K = c.K;
+    a.indptr = c.graph->indptr; a.indices = c.graph->indices; a.vals = c.graph->vals; a.X0 = c.E0; a.K = c.K;
     for (int k = 1; k < c.K; k++) a.Xl[k] = x->act[k];
-    a.n_users = c.n_users; a.N = c.N;
+    a.n_users = c.n_users; a.N = x->N;
     a.users = users + b_off; a.pos = pos + b_off; a.neg = neg + b_off;
     a.B_local = B_local; a.shard = shard;
     a.inv_B = 1.0f / (float)B_global; a.lam = c.decay / (float)B_global;
-    a.G64 = atomics ? (long long *)c.G64 : nullptr; a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
+    a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = c.bitmap; a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
     if (B_local <= 0) return 0;
     DISPATCH_D(c.d, {
-        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_bpr<D, float>), dim3(B_local), dim3(192), 0, st, a);
-        else hipLaunchKernelGGL((k_bpr<D, bf16_t>), dim3(B_local), dim3(192), 0, st, a);
+        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_bpr<D, float>), dim3(B_local), dim3(192 * BPR_BW), 0, st, a);
+        else hipLaunchKernelGGL((k_bpr<D, bf16_t>), dim3(B_local), dim3(192 * BPR_BW), 0, st, a);
     });
     return 0;
 }
 
-// finalize + backward chain + Adam + cleanup
+// [DP scatter] + backward chain + Adam + finish
 static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
                         const float *gathered, int32_t shard, int32_t world, float *loss_out, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     SlotArgs s{};
-    s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = c.N;
-    s.G64 = (long long *)c.G64; s.Gs = c.Gs; s.bitmap = c.bitmap; s.gathered = gathered; s.shard = shard; s.world = world;
-    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay; s.K = c.K;
+    s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
+    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap; s.gathered = gathered; s.shard = shard; s.world = world;
+    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
     const int spb = 256 / (c.d / 4);
     const unsigned sgrid = (unsigned)((3 * (int64_t)B + spb - 1) / spb);
     if (gathered) { DISPATCH_D(c.d, hipLaunchKernelGGL((k_scatter<D>), dim3(sgrid), dim3(256), 0, st, s)); }
-    DISPATCH_D(c.d, hipLaunchKernelGGL((k_finalize<D>), dim3(sgrid), dim3(256), 0, st, s));
 
     x->step += 1;
     const double bc1 = 1.0 - pow(c.beta1, (double)x->step);
     const double bc2 = 1.0 - pow(c.beta2, (double)x->step);
     // Horner: h_{K-1} = Gs + A Gs (sparse input); h_{k-1} = Gs + A h_k; last one feeds Adam
-    const void *prev = c.Gs; int prev_dt = LGCN_F32;
+    const void *prev = nullptr; int prev_dt = LGCN_F32;
     for (int k = c.K; k >= 1; k--) {
         SpmmArgs a = base_spmm(x);
         a.X = prev;
@@ -600,8 +869,7 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         void *y = nullptr;
         if (!last) {
             // ping-pong inside the activation workspace (forward activations are dead now)
-            y = x->act[1 + ((c.K - k) & 1)];
-            if (c.K == 2) y = x->act[1];
+            y = (c.K == 2) ? x->act[1] : x->act[1 + ((c.K - k) & 1)];
             a.Y = y;
         } else {
             a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
@@ -616,7 +884,7 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         if (rc) return rc;
         prev = y; prev_dt = c.act_dtype;
     }
-    DISPATCH_D(c.d, hipLaunchKernelGGL((k_cleanup<D>), dim3(sgrid), dim3(256), 0, st, s));
+    DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(sgrid), dim3(256), 0, st, s));
     return 0;
 }
 

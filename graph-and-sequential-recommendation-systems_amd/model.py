@@ -138,6 +138,8 @@ class LightGCN(nn.Module):
     def _drop_device_state(self):
         if self._dev is not None and self._dev.get('ctx'):
             _lib.load().lgcn_ctx_destroy(self._dev['ctx'])
+        if self._dev is not None and self._dev.get('graph') is not None:
+            self._dev['graph'].close()
         self._dev = None
         self._cache = None
 
@@ -156,9 +158,10 @@ class LightGCN(nn.Module):
         if self._dev is None:
             a = self._adj
             self._dev = {
-                'indptr': torch.from_numpy(np.ascontiguousarray(a.indptr, np.int32)).to(dev),
-                'indices': torch.from_numpy(np.ascontiguousarray(a.indices, np.int32)).to(dev),
-                'vals': torch.from_numpy(np.ascontiguousarray(a.data, np.float32)).to(dev),
+                'graph': _lib.Graph(torch.from_numpy(np.ascontiguousarray(a.indptr, np.int32)).to(dev),
+                                    torch.from_numpy(np.ascontiguousarray(a.indices, np.int32)).to(dev),
+                                    torch.from_numpy(np.ascontiguousarray(a.data, np.float32)).to(dev),
+                                    d_max=self.latent_dim),
                 'ctx': None, 'max_batch': 0,
             }
         st = self._dev
@@ -184,18 +187,17 @@ class LightGCN(nn.Module):
             st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
         st['act'] = torch.zeros(max(1, K - 1), N, d, dtype=tdt, device=dev)
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
-        st['Gs'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
         st['bitmap'] = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
         st['terms'] = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
         shard = (max_batch + dp_world - 1) // dp_world
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
         cfg = _lib.TrainConfig()
-        cfg.indptr, cfg.indices, cfg.vals = st['indptr'].data_ptr(), st['indices'].data_ptr(), st['vals'].data_ptr()
-        cfg.N, cfg.nnz, cfg.n_users, cfg.d, cfg.K = N, int(st['indices'].numel()), self.n_users, d, K
+        cfg.graph = st['graph'].handle
+        cfg.n_users, cfg.d, cfg.K = self.n_users, d, K
         cfg.act_dtype = act_dtype
         cfg.E0, cfg.adam_m, cfg.adam_v = self._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
-        cfg.act, cfg.G64, cfg.Gs = st['act'].data_ptr(), st['G64'].data_ptr(), st['Gs'].data_ptr()
+        cfg.act, cfg.G64 = st['act'].data_ptr(), st['G64'].data_ptr()
         cfg.bitmap, cfg.terms, cfg.contrib = st['bitmap'].data_ptr(), st['terms'].data_ptr(), st['contrib'].data_ptr()
         cfg.err, cfg.max_batch = st['err'].data_ptr(), max_batch
         cfg.decay = float(self.config.get('decay', 1e-4))
@@ -209,14 +211,7 @@ class LightGCN(nn.Module):
 
     # -- kernels ------------------------------------------------------------------------
     def _spmm(self, x):
-        st = self._state()
-        x = x.contiguous()
-        y = torch.empty_like(x, dtype=torch.float32)
-        N = self.n_users + self.m_items
-        _lib.check(_lib.load().lgcn_spmm_csr(_lib.tp(st['indptr']), _lib.tp(st['indices']), _lib.tp(st['vals']), N,
-                                             _lib.tp(x.float()), _lib.F32, _lib.tp(y), _lib.F32, self.latent_dim,
-                                             _lib.current_stream()), "lgcn_spmm_csr")
-        return y
+        return self._state()['graph'].spmm(x.float(), _lib.F32)
 
     def _propagate_dense(self):
         st = self._state()
@@ -228,9 +223,8 @@ class LightGCN(nn.Module):
             work = st['eval_work'] = torch.empty(K - 1, N, d, dtype=tdt, device=self._table.device)
         out = torch.empty(N, d, dtype=torch.float32, device=self._table.device)
         _lib.check(_lib.load().lgcn_propagate_mean(
-            _lib.tp(st['indptr']), _lib.tp(st['indices']), _lib.tp(st['vals']), N, _lib.tp(self._table), K, d,
-            act_dtype, _lib.tp(work) if K > 1 else None, _lib.tp(out), _lib.current_stream()),
-            "lgcn_propagate_mean")
+            st['graph'].handle, _lib.tp(self._table), K, d, act_dtype, _lib.tp(work) if K > 1 else None,
+            _lib.tp(out), _lib.current_stream()), "lgcn_propagate_mean")
         return out
 
     # -- reference API --------------------------------------------------------------------

@@ -90,20 +90,30 @@ int lgcn_build_norm_adj(int n_users, int m_items, const int64_t *r_indptr, const
                         int32_t *indptr, int32_t *indices, float *data);
 
 /* ------------------------------------------------------------------------ */
-/* Device: single kernels                                                     */
+/* Device: graph object + single kernels                                      */
 /* ------------------------------------------------------------------------ */
+/* The device-resident A_hat (what Loader.getSparseGraph returns, dataloader.py:203-246,
+ * here as CSR: int32 indptr[n_rows+1], int32 indices[nnz] sorted per row, fp32 vals[nnz]).
+ * The arrays are borrowed (must outlive the graph).  Creation is synchronous: it reads
+ * indptr back once to plan the splitting of long rows and allocates that plan's scratch
+ * (d_max = largest embedding dim that will be used with this graph).  One launch at a
+ * time per graph (the scratch is shared).                                             */
+typedef struct lgcn_graph lgcn_graph;   /* opaque */
+int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
+                      int64_t n_rows, int64_t nnz, int32_t d_max, lgcn_graph **out);
+void lgcn_graph_destroy(lgcn_graph *g);
+
 /* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217
  * (and its autograd backward A^T g: A_hat is symmetric).  X,Y: [n_rows,d]
  * row-major, fp32 or bf16 (x_dtype / y_dtype); d in {32,64,128,256}.           */
-int lgcn_spmm_csr(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t n_rows,
-                  const void *X, int x_dtype, void *Y, int y_dtype, int d, void *stream);
+int lgcn_spmm_csr(const lgcn_graph *g, const void *X, int x_dtype, void *Y, int y_dtype, int d,
+                  void *stream);
 
 /* out[N,d] fp32 = mean(X_0, A X_0, ..., A^K X_0) -- replaces LightGCN.computer()
  * model.py:201-231 (cat + K sparse.mm + stack + mean).  work: (K-1)*N*d elements
  * of act_dtype (may be NULL for K == 1).                                       */
-int lgcn_propagate_mean(const int32_t *indptr, const int32_t *indices, const float *vals, int64_t N,
-                        const float *E0, int K, int d, int act_dtype, void *work, float *out,
-                        void *stream);
+int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, int d, int act_dtype,
+                        void *work, float *out, void *stream);
 
 /* users/pos/neg[T] = S[perm[t], 0..2] -- the device side of utils.shuffle
  * (utils.py:150) applied to the sampler output (main.py:217-220).            */
@@ -118,12 +128,7 @@ int lgcn_apply_perm(const int32_t *S, int s_cols, const int64_t *perm, int64_t T
 typedef struct lgcn_ctx lgcn_ctx;   /* opaque */
 
 typedef struct {
-    /* graph: CSR of A_hat on the device (dataloader.py:203-246) */
-    const int32_t *indptr;      /* [N+1] */
-    const int32_t *indices;     /* [nnz] */
-    const float *vals;          /* [nnz] */
-    int64_t N;                  /* n_users + m_items */
-    int64_t nnz;
+    const lgcn_graph *graph;    /* A_hat, N = n_users + m_items rows */
     int32_t n_users;
     int32_t d;                  /* latent_dim_rec: 32/64/128/256 */
     int32_t K;                  /* lightGCN_n_layers: 1..LGCN_MAX_LAYERS */
@@ -135,9 +140,8 @@ typedef struct {
     float *adam_v;
     /* workspace, caller-allocated, zero-initialised before the first step */
     void *act;                  /* max(1,K-1) * N*d elements of act_dtype */
-    int64_t *G64;               /* [N,d] fixed-point gradient accumulator */
-    float *Gs;                  /* [N,d] sparse-row gradient G/(K+1) */
-    uint32_t *bitmap;           /* [ceil(N/32)] rows of Gs that are non-zero */
+    int64_t *G64;               /* [N,d] fixed-point (2^50) accumulator of the sparse-row gradient */
+    uint32_t *bitmap;           /* [ceil(N/32)] rows of G64 that are non-zero */
     float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
     float *contrib;             /* [3*max_batch*d + 2*max_batch] (data-parallel exchange buffer) or NULL */
     int32_t *err;               /* [1] device error flag */
