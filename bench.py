@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--workload", default="gowalla", choices=list(WORKLOADS))
     ap.add_argument("--act_dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--xcd_remap", type=int, default=1)
+    ap.add_argument("--row_order", default="cocluster", choices=["natural", "rcm", "cocluster"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
@@ -132,7 +133,8 @@ def main():
     w = pkg.world
     n_users, m_items, E, K, d, B = WORKLOADS[a.workload]
     w.configure(["--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B), "--act_dtype", a.act_dtype,
-                 "--xcd_remap", str(a.xcd_remap), "--tensorboard", "0", "--dataset", a.workload])
+                 "--xcd_remap", str(a.xcd_remap), "--row_order", a.row_order, "--tensorboard", "0",
+                 "--dataset", a.workload])
     data_dir = os.path.join(a.data_dir, f"{a.workload}_r{rank}")
     if a.workload == "gowalla" and os.path.exists(GOWALLA_NPZ):
         materialize_gowalla(GOWALLA_NPZ, data_dir)
@@ -208,7 +210,7 @@ def main():
                        "global_batch": Bg, "per_gpu_batch": B, "global_steps_per_sec": steps_per_sec,
                        "triplets_per_sec": steps_per_sec * Bg, "parallelism": f"dp{world} (replicated tables, "
                        "batch-sharded, gradient-row all-gather over RCCL)" if world > 1 else "single GPU",
-                       "act_dtype": a.act_dtype, "xcd_remap": a.xcd_remap,
+                       "act_dtype": a.act_dtype, "xcd_remap": a.xcd_remap, "row_order": a.row_order,
                        "first_loss": first_loss, "last_loss": last_loss},
             "step_algorithmic_bytes": step_bytes(N, nnz, d, s, K, B),
             "step_roofline_frac": step_bytes(N, nnz, d, s, K, B) * steps_per_sec / (HBM_PEAK_GBS * 1e9),
@@ -220,7 +222,7 @@ def main():
         st = model._state(max_batch=B, need_ctx=True, dp_world=world)
         adt = 0 if a.act_dtype == "fp32" else 1
         tdt = torch.float32 if adt == 0 else torch.bfloat16
-        x = (torch.randn(N, d, device=dev) * 0.1).to(tdt)
+        x = (torch.randn(N, d, device=dev) * 0.1).to(tdt)     # same graph object (same row order) as the step
         y = torch.empty_like(x)
         lib = L.load()
         stream = L.current_stream()

@@ -12,6 +12,7 @@ include/lgcn_hip.h (hand-written gfx950 kernels in csrc/).
     Procedure                  BPR_train_original, Test
     sampling                   the pybind11 `sampling` plugin's four functions
     parallel                   batch-sharded data parallel step over RCCL
+    reorder                    locality ordering of graph rows for the SpMM kernels
 
 The directory name contains '-', so import it with
     importlib.import_module("graph-and-sequential-recommendation-systems_amd")
@@ -21,7 +22,7 @@ exactly like the reference's world.py.
 import importlib as _importlib
 
 __all__ = ["build", "_lib", "world", "parse", "register", "dataloader", "model", "utils",
-           "Procedure", "sampling", "parallel"]
+           "Procedure", "sampling", "parallel", "reorder"]
 
 
 def __getattr__(name):

@@ -46,7 +46,7 @@ SIGNATURES = {
     "lgcn_build_user_item_csr": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgcn_adj_rowsum": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "lgcn_build_norm_adj": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_vp)]),
+    "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, C.POINTER(_vp)]),
     "lgcn_graph_destroy": (None, [_vp]),
     "lgcn_spmm_csr": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "lgcn_propagate_mean": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -132,7 +132,7 @@ def current_stream():
 class Graph:
     """Owner of an lgcn_graph handle over device CSR tensors (kept alive here)."""
 
-    def __init__(self, indptr, indices, vals, d_max=256):
+    def __init__(self, indptr, indices, vals, d_max=256, row_order=None):
         import torch
         require_gpu()
         self.indptr = indptr.to(torch.int32).contiguous()
@@ -146,9 +146,12 @@ class Graph:
             nnz = int(indices.numel())
         self.n_rows = int(self.indptr.numel()) - 1
         self.nnz = nnz
+        self.row_order = None
+        if row_order is not None:
+            self.row_order = torch.as_tensor(row_order).to(device=self.indptr.device, dtype=torch.int32).contiguous()
         h = _vp()
         check(load().lgcn_graph_create(tp(self.indptr), tp(self.indices), tp(self.vals), self.n_rows, nnz,
-                                       int(d_max), C.byref(h)), "lgcn_graph_create")
+                                       int(d_max), tp(self.row_order), C.byref(h)), "lgcn_graph_create")
         self.handle = h
 
     def spmm(self, x, y_dtype=None):

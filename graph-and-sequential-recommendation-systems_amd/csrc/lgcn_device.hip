@@ -147,28 +147,42 @@ __device__ __forceinline__ int tile_stage(int col, float val, int n, const Gathe
     return __popcll(mask);
 }
 
-// gather-accumulate the staged tile: group g takes entries g, g+NPW, ..., U in flight
-template <int D, typename TI, bool SPARSE>
-__device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
-    constexpr int LPR = D / 4, NPW = 64 / LPR, U = SPARSE ? 2 : LGCN_GATHER_U;   // few neighbours are active
+// One batch of U gathers per lane: entries j0+g, j0+g+NPW, ... of the staged tile.
+template <int D, typename TI, bool SPARSE, int U>
+__device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
+    constexpr int LPR = D / 4, NPW = 64 / LPR;
     typedef Raw<TI, SPARSE> R;
     const int g = lane / LPR, l = lane % LPR;
-    for (int j = g; j < cnt; j += NPW * U) {
-        int2 cv[U]; typename R::T x[U];
+    int2 cv[U]; typename R::T x[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {                                        // all LDS reads first
-            // past-the-end slots re-read the tile's last entry with weight 0: every gather is
-            // unconditional (a predicated load makes hipcc wait for the previous one)
-            const int e = j + u * NPW;
-            cv[u] = stage[min(e, cnt - 1)];
-            if (e >= cnt) cv[u].y = 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) x[u] = R::load(src, cv[u].x, D, l);      // U gathers in flight
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(x[u], src.div);
+    for (int u = 0; u < U; u++) {                                        // all LDS reads first
+        // past-the-end slots re-read the tile's last entry with weight 0: every gather is
+        // unconditional (a predicated load makes hipcc wait for the previous one)
+        const int e = j0 + g + u * NPW;
+        cv[u] = stage[min(e, cnt - 1)];
+        if (e >= cnt) cv[u].y = 0;
     }
+#pragma unroll
+    for (int u = 0; u < U; u++) x[u] = R::load(src, cv[u].x, D, l);      // U gathers in flight
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(x[u], src.div);
+}
+
+// Gather-accumulate the staged tile.  A 64-lane gather instruction costs the CU's L1 about
+// the same whether 1 or 4 of its row slots are useful (the kernel is bound by that issue rate,
+// not by bytes: bf16 rows are only ~10 % faster than fp32), so the batch depth follows the
+// (wave-uniform) number of staged neighbours instead of always issuing the deepest batch:
+// Gowalla's median row has 13 neighbours = 4 instructions, not 8.
+template <int D, typename TI, bool SPARSE>
+__device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
+    constexpr int NPW = 64 / (D / 4), UMAX = SPARSE ? 2 : LGCN_GATHER_U;
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    int j = 0;
+    if (UMAX >= 8) for (; cnt - j > 4 * NPW; j += 8 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 8 ? 8 : UMAX)>(stage, j, cnt, src, lane, acc);
+    if (UMAX >= 4) for (; cnt - j > 2 * NPW; j += 4 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 4 ? 4 : UMAX)>(stage, j, cnt, src, lane, acc);
+    for (; cnt - j > NPW; j += 2 * NPW) gather_batch<D, TI, SPARSE, 2>(stage, j, cnt, src, lane, acc);
+    if (cnt - j > 0) gather_batch<D, TI, SPARSE, 1>(stage, j, cnt, src, lane, acc);
 }
 
 template <int D>
@@ -228,6 +242,7 @@ struct LongPlan {
 
 struct SpmmArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
+    const int32_t *order;         // processing order of the rows (a permutation), or null = natural
     LongPlan lp;
     const void *X; void *Y;
     const long long *G64; const uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
@@ -313,43 +328,67 @@ __global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
         spmm_epilogue<D, TO, MODE>(a, row, lane, tot);
         return;
     }
-    // ---- SPMM_RW consecutive short rows per wave, walked one after the other; the first
-    //      index tile of row r+1 is in flight while row r gathers (hides two of the three
-    //      dependent round trips a 23-nnz row otherwise pays) ----
+    // ---- SPMM_RW short rows per wave, consecutive in the PROCESSING ORDER (a locality
+    //      ordering of the graph: rows that share neighbours run close together in time and on
+    //      the same XCD, so their gathers hit that XCD's L2; memory layout is untouched).  Rows
+    //      are walked one after the other; the first index tile of row r+1 is in flight while
+    //      row r gathers. ----
     const int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
     const int64_t tile = tile_of_block((int64_t)blockIdx.x - chunk_blocks, ntiles, a.remap);
     if (tile >= ntiles) return;
-    const int64_t row0 = (tile * 4 + wid) * SPMM_RW;
-    if (row0 >= a.n_rows) return;
-    const int my_ip = a.indptr[min(row0 + lane, a.n_rows)];      // SPMM_RW+1 row pointers, one load
-    int ip[SPMM_RW + 1];
+    const int64_t pos0 = (tile * 4 + wid) * SPMM_RW;
+    if (pos0 >= a.n_rows) return;
+    // lane r < SPMM_RW fetches row id and both row pointers of its row; then wave-uniform registers
+    int my_row = -1, my_s = 0, my_e = 0;
+    if (lane < SPMM_RW && pos0 + lane < a.n_rows) {
+        my_row = a.order ? a.order[pos0 + lane] : (int)(pos0 + lane);
+        my_s = a.indptr[my_row]; my_e = a.indptr[my_row + 1];
+    }
+    int rows[SPMM_RW], ip_s[SPMM_RW], ip_e[SPMM_RW];
 #pragma unroll
-    for (int r = 0; r <= SPMM_RW; r++) ip[r] = __builtin_amdgcn_readlane(my_ip, r);
+    for (int r = 0; r < SPMM_RW; r++) {
+        rows[r] = __builtin_amdgcn_readlane(my_row, r);
+        ip_s[r] = __builtin_amdgcn_readlane(my_s, r); ip_e[r] = __builtin_amdgcn_readlane(my_e, r);
+    }
     const bool split = a.lp.n_chunks > 0;
     int col_n = 0; float val_n = 0.f;
     {   // first tile of row 0
-        const int deg = ip[1] - ip[0];
-        if (!(split && deg > LONG_T) && lane < deg) { col_n = a.indices[ip[0] + lane]; val_n = a.vals[ip[0] + lane]; }
+        const int deg = ip_e[0] - ip_s[0];
+        if (!(split && deg > LONG_T) && lane < deg) { col_n = a.indices[ip_s[0] + lane]; val_n = a.vals[ip_s[0] + lane]; }
     }
+    f32x4 out[SPMM_RW];
+    unsigned live_mask = 0;
 #pragma unroll
     for (int r = 0; r < SPMM_RW; r++) {
-        const int64_t row = row0 + r;
-        const int start = ip[r], end = ip[r + 1];
-        const bool live = (row < a.n_rows) && !(split && end - start > LONG_T);   // long rows: done by chunks
+        const int start = ip_s[r], end = ip_e[r];
+        const bool live = (rows[r] >= 0) && !(split && end - start > LONG_T);   // long rows: done by chunks
         int cnt = 0;
         if (live) cnt = tile_stage<(MODE & M_SPARSE) != 0>(col_n, val_n, min(64, end - start), src, lane, stage_lds[wid]);
         __builtin_amdgcn_wave_barrier();
-        if (r + 1 < SPMM_RW && row + 1 < a.n_rows) {          // first tile of the next row: in flight during this row's gathers
-            const int ns = ip[r + 1], ndeg = ip[r + 2 <= SPMM_RW ? r + 2 : SPMM_RW] - ns;
+        if (r + 1 < SPMM_RW) {          // first tile of the next row: in flight during this row's gathers
+            const int ns = ip_s[r + 1 < SPMM_RW ? r + 1 : r], ndeg = ip_e[r + 1 < SPMM_RW ? r + 1 : r] - ns;
             if (!(split && ndeg > LONG_T) && lane < ndeg) { col_n = a.indices[ns + lane]; val_n = a.vals[ns + lane]; }
         }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (live) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_gather<D, TI, (MODE & M_SPARSE) != 0>(stage_lds[wid], cnt, src, lane, acc);
-            __builtin_amdgcn_wave_barrier();
-            acc = reduce_groups<D>(acc);
-            if (lane < LPR) spmm_epilogue<D, TO, MODE>(a, row, lane, acc);
+            live_mask |= 1u << r;
         }
+        __builtin_amdgcn_wave_barrier();
+        out[r] = reduce_groups<D>(acc);
+    }
+    // Epilogues last (a store between rows makes the next row's staging wait for it): group g
+    // finishes row q+g, all 64 lanes busy.
+    constexpr int NPW = 64 / LPR;
+    const int g = lane / LPR, l = lane % LPR;
+#pragma unroll
+    for (int q = 0; q < SPMM_RW; q += NPW) {
+        f32x4 mine = out[q];
+        int mrow = rows[q];
+#pragma unroll
+        for (int t = 1; t < NPW; t++) if (q + t < SPMM_RW && g == t) { mine = out[q + t]; mrow = rows[q + t]; }
+        const int r = q + g;
+        if (r < SPMM_RW && ((live_mask >> r) & 1u)) spmm_epilogue<D, TO, MODE>(a, mrow, l, mine);
     }
 }
 
@@ -655,7 +694,7 @@ extern "C" int lgcn_device_available(void) {
 // graph object: device CSR (borrowed) + the long-row plan and its scratch (owned)
 // ---------------------------------------------------------------------------------
 struct lgcn_graph {
-    const int32_t *indptr; const int32_t *indices; const float *vals;
+    const int32_t *indptr; const int32_t *indices; const float *vals; const int32_t *order;
     int64_t n_rows, nnz;
     int32_t d_max;
     LongPlan lp;
@@ -663,13 +702,24 @@ struct lgcn_graph {
 };
 
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
-                                 int64_t n_rows, int64_t nnz, int32_t d_max, lgcn_graph **out) {
+                                 int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
+                                 lgcn_graph **out) {
     if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
         n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
     if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
     std::vector<int32_t> ip((size_t)n_rows + 1);
     HIP_OK(hipMemcpy(ip.data(), indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost));
     if (ip[0] != 0 || (int64_t)ip[(size_t)n_rows] != nnz) { lgcn_set_error("lgcn_graph_create: indptr does not match nnz"); return 3; }
+    if (row_order) {             // must be a permutation of 0..n_rows-1
+        std::vector<int32_t> ord((size_t)n_rows);
+        HIP_OK(hipMemcpy(ord.data(), row_order, sizeof(int32_t) * ord.size(), hipMemcpyDeviceToHost));
+        std::vector<char> seen((size_t)n_rows, 0);
+        for (int64_t i = 0; i < n_rows; i++) {
+            const int32_t r = ord[(size_t)i];
+            if (r < 0 || r >= n_rows || seen[(size_t)r]) { lgcn_set_error("lgcn_graph_create: row_order is not a permutation"); return 3; }
+            seen[(size_t)r] = 1;
+        }
+    }
     std::vector<int32_t> long_row, chunk_ptr(1, 0), owner;
     for (int64_t r = 0; r < n_rows; r++) {
         const int64_t deg = (int64_t)ip[(size_t)r + 1] - ip[(size_t)r];
@@ -683,7 +733,8 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     }
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
-    g->indptr = indptr; g->indices = indices; g->vals = vals; g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
+    g->indptr = indptr; g->indices = indices; g->vals = vals; g->order = row_order;
+    g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
     g->owned = nullptr; g->lp = LongPlan{};
     const size_t n_long = long_row.size(), n_chunks = owner.size();
     if (n_long) {
@@ -715,7 +766,7 @@ extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
 
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.n_rows = g->n_rows; a.lp = g->lp;
+    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.order = g->order; a.n_rows = g->n_rows; a.lp = g->lp;
     return a;
 }
 

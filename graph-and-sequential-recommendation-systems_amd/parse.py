@@ -62,6 +62,8 @@ def build_parser():
                    help='NEW: storage type of propagated layer activations (accumulation is fp32)')
     p.add_argument('--xcd_remap', type=int, default=1,
                    help='NEW: give every XCD a contiguous range of graph rows')
+    p.add_argument('--row_order', type=str, default='cocluster', choices=['natural', 'rcm', 'cocluster'],
+                   help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
     p.add_argument('--data_path', type=str, default=None,
                    help='NEW: directory that holds <dataset>/train.txt (default: <root>/data)')
     return p

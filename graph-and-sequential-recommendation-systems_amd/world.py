@@ -97,6 +97,7 @@ def configure(argv=None):
     config['sampler'] = args.sampler
     config['act_dtype'] = args.act_dtype
     config['xcd_remap'] = args.xcd_remap
+    config['row_order'] = args.row_order
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

@@ -97,10 +97,13 @@ int lgcn_build_norm_adj(int n_users, int m_items, const int64_t *r_indptr, const
  * The arrays are borrowed (must outlive the graph).  Creation is synchronous: it reads
  * indptr back once to plan the splitting of long rows and allocates that plan's scratch
  * (d_max = largest embedding dim that will be used with this graph).  One launch at a
- * time per graph (the scratch is shared).                                             */
+ * time per graph (the scratch is shared).  row_order (device int32[n_rows], may be NULL)
+ * is an optional PROCESSING order of the rows -- a permutation chosen for L2 locality;
+ * it changes neither the memory layout nor any result bit.                             */
 typedef struct lgcn_graph lgcn_graph;   /* opaque */
 int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
-                      int64_t n_rows, int64_t nnz, int32_t d_max, lgcn_graph **out);
+                      int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
+                      lgcn_graph **out);
 void lgcn_graph_destroy(lgcn_graph *g);
 
 /* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217

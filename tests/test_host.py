@@ -237,3 +237,18 @@ def test_model_init_matches_reference_rng(pkg, tiny, tmp_path):
     m.load_state_dict(sd)
     assert m.embedding_user.weight.data_ptr() == m._table.data_ptr()
     assert np.allclose(m._table[:tiny.n_users].numpy(), tiny.z["E0_user"] + 1)
+
+
+def test_row_orders_are_permutations(pkg, tiny, lastfm, tmp_path):
+    for g in (tiny, lastfm):
+        ds = _load(pkg, g, tmp_path)
+        adj = ds.getSparseGraphCSR()
+        N = g.n_users + g.m_items
+        assert pkg.reorder.row_order('natural', ds, adj) is None
+        for method in ('rcm', 'cocluster'):
+            o = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)
+            assert o.dtype == np.int32 and np.array_equal(np.sort(o), np.arange(N)), method
+            assert os.path.exists(os.path.join(ds.path, f"s_row_order_{method}.npy"))
+            assert np.array_equal(o, pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path))   # cached
+    with pytest.raises(ValueError):
+        pkg.reorder.row_order('bogus', ds, adj)

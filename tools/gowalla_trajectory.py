@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Train Gowalla (BASELINE configs[1]: 3 layers, dim 64, batch 2048, seed 2020, cpp-mode
+sampler) for N epochs on the GPU through the product's own Procedure.BPR_train_original /
+Procedure.Test and print the trajectory next to the reference's (tests/golden/gowalla/
+golden_long.json, captured by importing the reference on CPU)."""
+import argparse, importlib, io, contextlib, json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bench import materialize_gowalla, GOWALLA_NPZ
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--epochs", type=int, default=10)
+ap.add_argument("--act_dtype", default="fp32")
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+sys.argv = [sys.argv[0]]
+import torch
+pkg = importlib.import_module("graph-and-sequential-recommendation-systems_amd")
+w = pkg.world
+w.configure(["--dataset", "gowalla", "--tensorboard", "0", "--act_dtype", a.act_dtype,
+             "--checkpoint_dir", "/tmp/lgcn_traj_ckpt"])
+d = materialize_gowalla(GOWALLA_NPZ, "/tmp/lgcn_traj_gowalla")
+ref = json.load(open(os.path.join(REPO, "tests", "golden", "gowalla", "golden_long.json")))
+with contextlib.redirect_stdout(io.StringIO()):
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    pkg.sampling.seed(w.seed); pkg.utils.set_seed(w.seed)
+    model = pkg.model.LightGCN(w.config, ds).to(w.device)
+    bpr = pkg.utils.BPRLoss(model, w.config)
+    r0 = pkg.Procedure.Test(ds, model, 0)
+rows = [{"epoch": 0, "test": {k: float(v[0]) for k, v in r0.items()}, "ref_test": {k: v[0] for k, v in ref["test_epoch0"].items()}}]
+t_train = 0.0
+for e in range(1, a.epochs + 1):
+    torch.cuda.synchronize(); t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        info = pkg.Procedure.BPR_train_original(ds, model, bpr, e)
+    torch.cuda.synchronize(); dt = time.time() - t0; t_train += dt
+    rt = ref["trajectory"][e - 1] if e <= len(ref["trajectory"]) else {}
+    row = {"epoch": e, "info": info, "seconds": dt, "ref_avg_loss": rt.get("avg_loss"), "ref_steps": rt.get("steps")}
+    if "test" in rt or e == a.epochs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = pkg.Procedure.Test(ds, model, e)
+        row["test"] = {k: float(v[0]) for k, v in r.items()}
+        if "test" in rt:
+            row["ref_test"] = {k: v[0] for k, v in rt["test"].items()}
+            row["abs_diff"] = {k: abs(row["test"][k] - row["ref_test"][k]) for k in row["test"]}
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+print(json.dumps({"epochs": a.epochs, "train_seconds_total": t_train, "act_dtype": a.act_dtype}))
+if a.out:
+    json.dump(rows, open(a.out, "w"), indent=1)
