@@ -1,0 +1,99 @@
+"""N>1 path on CPU: two gloo ranks exercise the data-parallel exchange of parallel.py (shard
+bounds, per-rank block layout [3*S*d | S | S], the all-gather) with gradient rows computed by the
+oracle, and check that the gathered blocks reduce to the oracle's single-process gradient G and
+loss for the global batch.  The HIP kernels that produce / consume these blocks are covered on the
+GPU by test_gpu_parity.py::test_bitwise_reproducible_and_dp_split."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, PKG_NAME, GoldenSet
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rows_and_terms(orc, E, g, users, pos, neg, B_global, decay):
+    """Per-triplet gradient rows (slot-major [3,b,d]) and loss terms, by finite assembly from the oracle:
+    the oracle's bpr() on ONE triplet with inv_B and lambda of the GLOBAL batch."""
+    d = E.shape[1]
+    rows = np.zeros((3, len(users), d), np.float32)
+    lt = np.zeros(len(users), np.float32); rt = np.zeros(len(users), np.float32)
+    for i, (u, p, n) in enumerate(zip(users, pos, neg)):
+        eu, ep, en = E[u], E[g.n_users + p], E[g.n_users + n]
+        x = np.float32(eu @ ep) - np.float32(eu @ en)
+        z = np.exp(-abs(x)); sig_neg = (1 / (1 + z)) if x < 0 else z / (1 + z)
+        gb = np.float32(-(1.0 / B_global) * sig_neg); lam = np.float32(decay / B_global)
+        rows[0, i] = gb * (ep - en) + lam * eu
+        rows[1, i] = gb * eu + lam * ep
+        rows[2, i] = -gb * eu + lam * en
+        lt[i] = min(x, 0) - np.log1p(z)
+        rt[i] = eu @ eu + ep @ ep + en @ en
+    return rows, lt, rt
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG_NAME)
+    from oracle import oracle as orc
+    g = GoldenSet("tiny")
+    E = orc.propagate(g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"], g.e0(), g.K)
+    rng = np.random.Generator(np.random.PCG64(0))
+    B = 37                                                   # ragged: shards of 19 and 18
+    users = rng.integers(0, g.n_users, B); pos = rng.integers(0, g.m_items, B); neg = rng.integers(0, g.m_items, B)
+    par = pkg.parallel
+    S = par.shard_size(B, world)
+    lo, hi = par.shard_bounds(B, world, rank)
+    rows, lt, rt = _rows_and_terms(orc, E, g, users[lo:hi], pos[lo:hi], neg[lo:hi], B, g.meta["decay"])
+    block = np.zeros(par.block_numel(B, world, g.d), np.float32)
+    blk_rows = block[:3 * S * g.d].reshape(3, S, g.d)
+    blk_rows[:, :hi - lo] = rows
+    block[3 * S * g.d:3 * S * g.d + (hi - lo)] = lt
+    block[3 * S * g.d + S:3 * S * g.d + S + (hi - lo)] = rt
+    gathered = par.exchange(torch.from_numpy(block)).numpy()
+    # every rank reduces all blocks exactly as k_scatter / k_finish index them
+    blk = par.block_numel(B, world, g.d)
+    G = np.zeros_like(E, dtype=np.float64); fl = fr = 0.0
+    for b in range(B):
+        r, i = b // S, b % S
+        base = r * blk
+        for c, row in ((0, users[b]), (1, g.n_users + pos[b]), (2, g.n_users + neg[b])):
+            G[row] += gathered[base + (c * S + i) * g.d: base + (c * S + i + 1) * g.d]
+        fl += gathered[base + 3 * S * g.d + i]; fr += gathered[base + 3 * S * g.d + S + i]
+    bpr, reg, G_ref = orc.bpr(E, g.n_users, users, pos, neg, g.meta["decay"])
+    ok = (np.allclose(G, G_ref, rtol=1e-5, atol=1e-9) and abs(-fl / B - bpr) < 1e-6 and abs(0.5 * fr / B - reg) < 1e-6
+          and gathered.shape[0] == world * blk)
+    t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(out, "w").write(str(int(t.item())))
+    dist.destroy_process_group()
+
+
+def test_dp_exchange_two_gloo_ranks(tmp_path):
+    out = os.path.join(str(tmp_path), "ok.txt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "1"
+
+
+def test_shard_bounds(pkg):
+    par = pkg.parallel
+    for B in (1, 7, 37, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            S = par.shard_size(B, world)
+            cover = []
+            for r in range(world):
+                lo, hi = par.shard_bounds(B, world, r)
+                assert 0 <= lo <= hi <= B and hi - lo <= S
+                cover.extend(range(lo, hi))
+            assert cover == list(range(B))
+            assert par.block_numel(B, world, 64) == 3 * S * 64 + 2 * S
