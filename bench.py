@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--xcd_remap", type=int, default=1)
     ap.add_argument("--row_order", default="cocluster", choices=["natural", "rcm", "cocluster"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--force_dp", action="store_true", help="use the data-parallel step (RCCL all-gather) even at world size 1")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
     a = ap.parse_args()
@@ -124,9 +125,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or a.force_dp
+    if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     sys.argv = [sys.argv[0]]
     pkg = importlib.import_module(PKG)
@@ -162,7 +165,7 @@ def main():
         us.append(u); ps.append(p); ns.append(n); have += len(u)
     users, pos, neg = torch.cat(us)[:need], torch.cat(ps)[:need], torch.cat(ns)[:need]
 
-    if world == 1:
+    if not use_dp:
         def run(lo, steps):
             return model.fused_epoch(users[lo:lo + steps * B], pos[lo:lo + steps * B], neg[lo:lo + steps * B], B)
     else:
@@ -177,7 +180,7 @@ def main():
             return torch.stack(out)
 
     def barrier():
-        if world > 1:
+        if use_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +190,7 @@ def main():
     losses = run(a.warmup * Bg, a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +212,7 @@ def main():
                                    f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d}, bpr_batch={B} per GPU",
                        "global_batch": Bg, "per_gpu_batch": B, "global_steps_per_sec": steps_per_sec,
                        "triplets_per_sec": steps_per_sec * Bg, "parallelism": f"dp{world} (replicated tables, "
-                       "batch-sharded, gradient-row all-gather over RCCL)" if world > 1 else "single GPU",
+                       "batch-sharded, gradient-row all-gather over RCCL)" if use_dp else "single GPU",
                        "act_dtype": a.act_dtype, "xcd_remap": a.xcd_remap, "row_order": a.row_order,
                        "first_loss": first_loss, "last_loss": last_loss},
             "step_algorithmic_bytes": step_bytes(N, nnz, d, s, K, B),
@@ -277,7 +280,7 @@ def main():
                                          "steps/s on 8 cores (BASELINE.md)"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -390,3 +390,48 @@ def test_gowalla_10_epoch_trajectory_vs_reference(pkg, tmp_path, act_dtype):
                 assert abs(float(r[k][0]) - rec["test"][k][0]) < 1e-4, (act_dtype, e, k, r[k], rec["test"][k])
             if act_dtype == "fp32":
                 assert abs(float(r["recall"][0]) - rec["test"]["recall"][0]) < 1e-6
+
+
+def _write_synth(path, n_users, m_items, seed, max_deg):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "train.txt"), "w") as f, open(os.path.join(path, "test.txt"), "w") as ft:
+        for u in range(n_users):
+            k = int(rng.integers(1, max_deg)) if u % 37 else min(m_items - 1, 6 * max_deg)      # some long rows
+            items = np.sort(rng.choice(m_items, size=k, replace=False))
+            f.write(f"{u} " + " ".join(map(str, items.tolist())) + "\n")
+            ft.write(f"{u} {int(rng.integers(0, m_items))}\n")
+        f.write(f"{n_users - 1} {m_items - 1}\n") if False else None
+
+
+@pytest.mark.parametrize("d,K,act", [(32, 2, "fp32"), (128, 4, "fp32"), (256, 3, "fp32"), (128, 3, "bf16")])
+def test_fused_steps_other_dims_vs_oracle(pkg, oracle, tmp_path, d, K, act):
+    """BASELINE configs[3]/[4] shapes in miniature: dim 128 (4 layers) and 256, plus dim 32, on a
+    synthetic bipartite graph with split (long) rows: 3 fused steps vs the oracle's stageOne."""
+    path = os.path.join(str(tmp_path), f"synth{d}")
+    _write_synth(path, 700, 900, d, 24)
+    w = pkg.world
+    w.configure(["--dataset", "synth", "--tensorboard", "0", "--layer", str(K), "--recdim", str(d),
+                 "--bpr_batch", "256", "--act_dtype", act, "--row_order", "rcm"])
+    ds = pkg.dataloader.Loader(w.config, path=path)
+    pkg.utils.set_seed(7)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    adj = ds.getSparseGraphCSR()
+    e0 = m._table.cpu().numpy().copy()
+    tr = oracle.Trainer(ds.n_users, adj.indptr, adj.indices, adj.data, e0, K, w.config['decay'], w.config['lr'])
+    bpr = pkg.utils.BPRLoss(m, w.config)
+    rng = np.random.Generator(np.random.PCG64(1))
+    tol = 3e-6 if act == "fp32" else 3e-4
+    for step in range(3):
+        nb = [256, 256, 100][step]
+        u = rng.integers(0, ds.n_users, nb); p = rng.integers(0, ds.m_items, nb); n = rng.integers(0, ds.m_items, nb)
+        l_ref = tr.stageOne(u, p, n)
+        l_got = bpr.stageOne(_dev(u), _dev(p), _dev(n))
+        assert abs(l_got - l_ref) < tol * 10, (step, l_got, l_ref)
+        np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=tol if act == "fp32" else 2e-3)
+    with torch.no_grad():
+        au, ai = m.computer()
+    ref = oracle.propagate(adj.indptr, adj.indices, adj.data, tr.e0, K)
+    np.testing.assert_allclose(torch.cat([au, ai]).cpu().numpy(), ref, rtol=2e-5 if act == "fp32" else 3e-2,
+                               atol=2e-6 if act == "fp32" else 3e-3)
+    m.check_device_errors()
