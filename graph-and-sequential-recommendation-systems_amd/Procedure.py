@@ -108,38 +108,65 @@ def _batch_metrics(hits, gt_len, topks):
     return out
 
 
+class _EvalIndex:
+    """Device-resident CSR of the train positives and of the test lists, built once per dataset:
+    the per-batch Python loops of Procedure.py:170-181 become two index_put calls."""
+
+    def __init__(self, dataset, dev):
+        indptr, indices = dataset.pos_csr() if hasattr(dataset, 'pos_csr') else utils._pos_csr(dataset)
+        self.users = np.fromiter(dataset.testDict.keys(), dtype=np.int64, count=len(dataset.testDict))
+        self.train_ptr = torch.from_numpy(np.ascontiguousarray(indptr, np.int64)).to(dev)
+        self.train_idx = torch.from_numpy(np.ascontiguousarray(indices, np.int64)).to(dev)
+        lens = np.fromiter((len(dataset.testDict[u]) for u in self.users.tolist()), dtype=np.int64, count=len(self.users))
+        ptr = np.zeros(len(self.users) + 1, np.int64); np.cumsum(lens, out=ptr[1:])
+        items = np.concatenate([np.asarray(dataset.testDict[u], np.int64) for u in self.users.tolist()]) if len(self.users) else np.zeros(0, np.int64)
+        self.test_len = lens
+        self.test_ptr = torch.from_numpy(ptr).to(dev)
+        self.test_idx = torch.from_numpy(items).to(dev)
+
+    @staticmethod
+    def _expand(ptr, rows):
+        """(local row id, position) pairs of the CSR rows `rows`."""
+        start, end = ptr[rows], ptr[rows + 1]
+        lens = end - start
+        local = torch.repeat_interleave(torch.arange(len(rows), device=ptr.device), lens)
+        offs = torch.arange(int(lens.sum()), device=ptr.device) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+        return local, torch.repeat_interleave(start, lens) + offs
+
+
 def Test(dataset, Recmodel, epoch, w=None, multicore=0):
     """Procedure.py:127-206 (multicore is accepted and ignored: the reference creates a Pool
-    and never uses it)."""
+    and never uses it).  Per-user results do not depend on the user batch size, so
+    several `test_u_batch_size` batches are scored per launch (bounded by ~1 GiB of scores)."""
     u_batch_size = world.config['test_u_batch_size']
-    testDict = dataset.testDict
     Recmodel = Recmodel.eval()
     max_K = max(world.topks)
     if hasattr(Recmodel, "invalidate_cache"):
         Recmodel.invalidate_cache()
     dev = world.device
+    ev = getattr(dataset, '_lgcn_eval_index', None)
+    if ev is None or ev.train_ptr.device != torch.empty(0, device=dev).device:
+        ev = _EvalIndex(dataset, dev)
+        try:
+            dataset._lgcn_eval_index = ev
+        except Exception:
+            pass
     per_user = {m: [] for m in ('precision', 'recall', 'ndcg')}
+    chunk = max(u_batch_size, min(8192, (1 << 28) // max(1, dataset.m_items)) // u_batch_size * u_batch_size)
     with torch.no_grad():
-        users = list(testDict.keys())
-        indptr, indices = dataset.pos_csr() if hasattr(dataset, 'pos_csr') else utils._pos_csr(dataset)
-        for (batch_users,) in utils.minibatch(users, batch_size=u_batch_size):
-            bu = np.asarray(batch_users, np.int64)
-            batch_gpu = torch.from_numpy(bu).to(dev)
+        users_dev = torch.from_numpy(ev.users).to(dev)
+        for s in range(0, len(ev.users), chunk):
+            batch_gpu = users_dev[s:s + chunk]
             rating_K = Recmodel.getUsersRating(batch_gpu)
-            # mask seen interactions (Procedure.py:177-181)
-            lens = (indptr[bu + 1] - indptr[bu]).astype(np.int64)
-            ex_idx = np.repeat(np.arange(len(bu)), lens)
-            ex_items = np.concatenate([indices[indptr[u]:indptr[u + 1]] for u in bu]) if lens.sum() else np.zeros(0, np.int64)
-            rating_K[torch.from_numpy(ex_idx).to(dev), torch.from_numpy(ex_items.astype(np.int64)).to(dev)] = -(1 << 10)
+            ex_row, ex_pos = ev._expand(ev.train_ptr, batch_gpu)           # mask seen interactions
+            rating_K[ex_row, ev.train_idx[ex_pos]] = -(1 << 10)             # (Procedure.py:177-181)
             _, topk = torch.topk(rating_K, k=max_K)
-            # labels: is top-k item in the user's test list?
-            gt_len = np.array([len(testDict[u]) for u in batch_users], np.int64)
-            gt_idx = np.repeat(np.arange(len(bu)), gt_len)
-            gt_items = np.concatenate([np.asarray(testDict[u], np.int64) for u in batch_users])
+            rows = torch.arange(s, min(s + chunk, len(ev.users)), device=dev)
+            gt_row, gt_pos = ev._expand(ev.test_ptr, rows)
             is_gt = torch.zeros(rating_K.shape, dtype=torch.bool, device=dev)
-            is_gt[torch.from_numpy(gt_idx).to(dev), torch.from_numpy(gt_items).to(dev)] = True
+            is_gt[gt_row, ev.test_idx[gt_pos]] = True
             hits = is_gt.gather(1, topk).cpu().numpy()
-            bm = _batch_metrics(hits, gt_len, world.topks)
+            bm = _batch_metrics(hits, ev.test_len[s:s + chunk], world.topks)
             for m in per_user:
                 per_user[m].append(bm[m])
     results = {m: np.mean(np.concatenate(per_user[m], 0), axis=0) for m in per_user}

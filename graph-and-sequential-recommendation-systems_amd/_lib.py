@@ -23,7 +23,7 @@ class TrainConfig(C.Structure):
         ("graph", _vp),
         ("n_users", C.c_int32), ("d", C.c_int32), ("K", C.c_int32), ("act_dtype", C.c_int32),
         ("E0", _vp), ("adam_m", _vp), ("adam_v", _vp),
-        ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("contrib", _vp),
+        ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("ebuf", _vp), ("contrib", _vp),
         ("err", _vp), ("max_batch", C.c_int32),
         ("decay", C.c_float),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),

@@ -245,8 +245,12 @@ struct SpmmArgs {
     const int32_t *order;         // processing order of the rows (a permutation), or null = natural
     LongPlan lp;
     const void *X; void *Y;
-    const long long *G64; const uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
+    long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
     float *P; float *M; float *V;
+    // last kernel of a step (K >= 2): its epilogue zeroes the G64 rows / bitmap bits it consumes and one
+    // wave reduces the per-triplet loss terms, so no separate clean-up launch is needed
+    int clear;
+    const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
     int64_t n_rows;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
@@ -262,6 +266,13 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
     if ((MODE & M_ADDG) && bit_set(a.bitmap, (int)row)) {
         f32x4 g = load4_fixed(a.G64 + off, a.div);
         acc = g + acc;
+        if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
+            // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
+            //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
+            //  k_bpr_loss of the next step zeroes the stale one with plain stores)
+            i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
+            q[0] = i64x2{0, 0}; q[1] = i64x2{0, 0};
+        }
     }
     if (MODE & M_ADAM) {
         f32x4 p = load4(a.P + off), m = load4(a.M + off), v = load4(a.V + off);
@@ -277,6 +288,30 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
     }
 }
 
+// deterministic reduction of the per-triplet loss / reg terms by ONE wave (fixed strided
+// partials, then an xor-shuffle tree): loss_out = {bpr + decay*reg, bpr, reg}   (model.py:168-173)
+__device__ __forceinline__ void reduce_loss_wave(const float *terms, const float *gathered, int B, int shard,
+                                                 int D, float decay, float *loss_out, int lane) {
+    float fl = 0.f, fr = 0.f;
+    if (gathered) {
+        const int64_t blk = (int64_t)3 * shard * D + 2 * shard;
+        for (int b = lane; b < B; b += 64) {
+            const float *t = gathered + (b / shard) * blk + (int64_t)3 * shard * D;
+            fl += t[b % shard]; fr += t[shard + b % shard];
+        }
+    } else {
+#pragma unroll 8
+        for (int b = lane; b < B; b += 64) { fl += terms[b]; fr += terms[B + b]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { fl += __shfl_xor(fl, off); fr += __shfl_xor(fr, off); }
+    if (lane == 0) {
+        const float bpr = -(fl / (float)B);
+        const float reg = (0.5f * fr) / (float)B;
+        loss_out[0] = bpr + decay * reg; loss_out[1] = bpr; loss_out[2] = reg;
+    }
+}
+
 // Y = [Gs +] A_hat X.  256-thread workgroups = 4 waves.  Blocks [0, chunk_blocks) run one
 // long-row chunk per wave, the remaining blocks one short row per wave.
 //   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
@@ -286,6 +321,10 @@ __global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
     __shared__ int2 stage_lds[4][64];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
+    //  sat on the tail and cost +25 us)
+    if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear && blockIdx.x == 0 && wid == 3)
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane);
     GatherSrc src;
     src.X = (MODE & M_SPARSE) ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
     const int chunk_blocks = (a.lp.n_chunks + 3) >> 2;
@@ -425,15 +464,18 @@ __global__ void __launch_bounds__(256) k_spmm_mean(MeanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// Fused BPR: one 768-thread workgroup per triplet = 3 slots (0 user, 1 positive item,
-// 2 negative item) x BW = 4 waves.  The 4 waves of a slot split the slot's CSR row into
-// contiguous quarters of 64-entry tiles (popular items have 1000+ neighbours: one wave
-// alone would be the critical path of the whole launch) and meet in LDS.
-//   1. e_c = mean_k X_k[row_c]; X_K[row_c] is computed on the fly from X_{K-1}
-//   2. x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ; r = |e_u|^2+|e_p|^2+|e_n|^2
-//   3. gradient row of slot c wrt the propagated table -> either
-//      fixed-point atomics into G64 + bitmap flag (single GPU) or the exchange
-//      buffer (data parallel).
+// BPR on the batch, two launches (the fused one-workgroup-per-triplet form kept a CU at 2
+// resident workgroups and took 30 us; split, every slot row is its own small workgroup).
+//
+// k_rows: one 256-thread workgroup per slot (3B slots: user, positive item, negative item of
+//   every triplet).  e = mean_k X_k[row]; the last layer X_K[row] = (A_hat X_{K-1})[row] is
+//   computed on the fly.  The 4 waves split the row's 64-entry tiles (positives are sampled
+//   proportionally to popularity: 1000-neighbour rows are common); a wave without work ends
+//   at once (s_barrier counts only surviving waves), so a typical slot costs one wave.
+// k_bpr_loss: one lane group per triplet: x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
+//   r = |e_u|^2+|e_p|^2+|e_n|^2 ; the three gradient rows w.r.t. the propagated table
+//    -> fixed-point atomics into G64 + bitmap flag (single GPU) or the
+//   exchange buffer (data parallel).
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -444,8 +486,10 @@ struct BprArgs {
     int32_t shard;        // row stride of the contrib block (>= B_local)
     float inv_B;          // 1 / global batch
     float lam;            // decay / global batch
+    float *ebuf;          // [3, B_local, D] propagated rows of the slots
     long long *G64;       // if non-null: atomics
     uint32_t *bitmap;
+    uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
     float *contrib;       // else: [3*shard*D | shard | shard]
     float *terms;         // single GPU: [2*B]  (loss terms, reg terms)
     int32_t *err;
@@ -465,87 +509,101 @@ __device__ __forceinline__ void atomic_add_fixed4(long long *dst, f32x4 g) {
     atomicAdd(d + 3, (unsigned long long)__double2ll_rn((double)g.w * FIXED_SCALE));
 }
 
+__device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
+    const int u = a.users[b], p = a.pos[b], n = a.neg[b];
+    return u < 0 || u >= a.n_users || p < 0 || (int64_t)p + a.n_users >= a.N || n < 0 || (int64_t)n + a.n_users >= a.N;
+}
+
+#ifndef BPR_BW
 #define BPR_BW 4
+#endif
 template <int D, typename TI>
-__global__ void __launch_bounds__(192 * BPR_BW) k_bpr(BprArgs a) {
+__global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
     constexpr int LPR = D / 4;
-    __shared__ int2 stage_lds[3 * BPR_BW][64];
-    __shared__ __attribute__((aligned(16))) float part_lds[3 * BPR_BW][D];
-    __shared__ __attribute__((aligned(16))) float e_lds[3][D];
+    __shared__ int2 stage_lds[BPR_BW][64];
+    __shared__ __attribute__((aligned(16))) float part_lds[BPR_BW][D];
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 .. 3*BW-1
-    const int c = wv / BPR_BW, q = wv % BPR_BW;
-    const int b = blockIdx.x;
-    int64_t row;
-    bool bad = false;
-    if (c == 0) { int u = a.users[b]; bad = (u < 0 || u >= a.n_users); row = u; }
-    else {
-        int it = (c == 1) ? a.pos[b] : a.neg[b];
-        bad = (it < 0 || (int64_t)it + a.n_users >= a.N); row = (int64_t)it + a.n_users;
-    }
-    if (bad) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
+    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
+    if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
     const int start = a.indptr[row], end = a.indptr[row + 1];
-    // quarter q of the row's 64-entry tiles
     const int tiles = (end - start + 63) >> 6, per = (tiles + BPR_BW - 1) / BPR_BW;
+    const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
+    if (q >= nparts) return;
     const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
     GatherSrc src; src.bm = nullptr; src.div = 1.f;
     f32x4 xk;
-    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wv]); }
-    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wv]); }
-    if (lane < LPR) store4(&part_lds[wv][lane * 4], xk);
-    __syncthreads();
-    if (q == 0 && lane < LPR) {
+    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[q]); }
+    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[q]); }
+    if (nparts > 1) {
+        if (lane < LPR) store4(&part_lds[q][lane * 4], xk);
+        __syncthreads();
+        if (q != 0) return;
+        if (lane < LPR) {
+            xk = load4(&part_lds[0][lane * 4]);
+            for (int w = 1; w < nparts; w++) xk += load4(&part_lds[w][lane * 4]);
+        }
+    }
+    if (lane < LPR) {
         const int64_t off = row * D + lane * 4;
         f32x4 s = load4(a.X0 + off);
         for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + off);
-        f32x4 t = load4(&part_lds[c * BPR_BW][lane * 4]);
-#pragma unroll
-        for (int w = 1; w < BPR_BW; w++) t += load4(&part_lds[c * BPR_BW + w][lane * 4]);
-        s += t;
+        s += xk;
         const float div = (float)(a.K + 1);
-        store4(&e_lds[c][lane * 4], s / div);
+        store4(a.ebuf + (int64_t)blockIdx.x * D + lane * 4, s / div);
     }
-    __syncthreads();
-    if (q != 0) return;
-    // wave (c,0) finishes slot c; the (cheap) dots are recomputed by each of the three
-    f32x4 u4 = {0, 0, 0, 0}, p4 = u4, n4 = u4;
-    if (lane < LPR) {
-        u4 = load4(&e_lds[0][lane * 4]); p4 = load4(&e_lds[1][lane * 4]); n4 = load4(&e_lds[2][lane * 4]);
-    }
-    float ps = u4.x * p4.x + u4.y * p4.y + u4.z * p4.z + u4.w * p4.w;
-    float ns = u4.x * n4.x + u4.y * n4.y + u4.z * n4.z + u4.w * n4.w;
-    float rr = (u4.x * u4.x + u4.y * u4.y + u4.z * u4.z + u4.w * u4.w) +
-               (p4.x * p4.x + p4.y * p4.y + p4.z * p4.z + p4.w * p4.w) +
-               (n4.x * n4.x + n4.y * n4.y + n4.z * n4.z + n4.w * n4.w);
+}
+
+// Lane = column (mod 64): every load, store and atomic wave-instruction of a triplet covers
+// min(D,64) contiguous elements -- 512 contiguous bytes per 64-bit atomic instruction at d=64.
+// (With 4 columns per lane the same atomics were 16 lanes x 8 B at a 32-byte stride and cost
+// 9 of this kernel's 13.7 us.)
+template <int D>
+__global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
+    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT, TPB = 256 / LPT;     // lanes per triplet, columns per lane
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
+        a.stale_bitmap[i] = 0u;
+    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
+    if (b >= a.B_local) return;                 // whole lane groups leave together
+    float u[CPL], p[CPL], n[CPL];
+    float ps = 0.f, ns = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
 #pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) {
+    for (int j = 0; j < CPL; j++) {
+        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
+        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
+        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
+        ps += u[j] * p[j]; ns += u[j] * n[j]; ru += u[j] * u[j]; rp += p[j] * p[j]; rn += n[j] * n[j];
+    }
+    float rr = ru + rp + rn;
+#pragma unroll
+    for (int off = 1; off < LPT; off <<= 1) {
         ps += __shfl_xor(ps, off); ns += __shfl_xor(ns, off); rr += __shfl_xor(rr, off);
     }
-    // an out-of-range id anywhere in the triplet voids the whole triplet
-    const bool tbad = (a.users[b] < 0 || a.users[b] >= a.n_users || a.pos[b] < 0 || (int64_t)a.pos[b] + a.n_users >= a.N ||
-                       a.neg[b] < 0 || (int64_t)a.neg[b] + a.n_users >= a.N);
+    const bool tbad = triplet_bad(a, b);        // an out-of-range id voids the whole triplet
     const float x = ps - ns;
     const float gb = tbad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
-    if (c == 0 && lane == 0) {
+    if (l == 0) {
         float *lt = a.G64 ? a.terms : a.contrib + (int64_t)3 * a.shard * D;
         const int stride = a.G64 ? a.B_local : a.shard;
         lt[b] = tbad ? 0.f : logsigmoid_f(x);
         lt[stride + b] = tbad ? 0.f : rr;
     }
-    if (lane < LPR) {
-        f32x4 g;
-        if (c == 0) g = gb * (p4 - n4) + a.lam * u4;
-        else if (c == 1) g = gb * u4 + a.lam * p4;
-        else g = (-gb) * u4 + a.lam * n4;
-        if (tbad) g = f32x4{0, 0, 0, 0};
-        if (a.G64) {
-            if (!tbad) {
-                atomic_add_fixed4(a.G64 + row * D + lane * 4, g);
-                if (lane == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+    if (a.G64 && tbad) return;
+    const int64_t rows[3] = {(int64_t)a.users[b], (int64_t)a.pos[b] + a.n_users, (int64_t)a.neg[b] + a.n_users};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            float g = c == 0 ? gb * (p[j] - n[j]) + a.lam * u[j] : (c == 1 ? gb * u[j] + a.lam * p[j] : (-gb) * u[j] + a.lam * n[j]);
+            if (a.G64) {
+                atomicAdd((unsigned long long *)(a.G64 + rows[c] * D + j * LPT + l),
+                          (unsigned long long)__double2ll_rn((double)g * FIXED_SCALE));
+            } else {
+                a.contrib[((int64_t)c * a.shard + b) * D + j * LPT + l] = tbad ? 0.f : g;
             }
-        } else {
-            store4(a.contrib + ((int64_t)c * a.shard + b) * D + lane * 4, g);
         }
+        if (a.G64 && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
     }
 }
 
@@ -829,6 +887,8 @@ struct lgcn_ctx {
     lgcn_train_config c;
     int64_t step;
     int64_t N;
+    int64_t bm_words;             // words per bitmap; cfg.bitmap holds two, used alternately
+    int flip;
     void *act[LGCN_MAX_LAYERS];   // act[k] = X_k storage for k = 1..K-1 (also reused for H)
 };
 
@@ -836,7 +896,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!cfg || !out) { lgcn_set_error("lgcn_ctx_create: null argument"); return 3; }
     const lgcn_train_config &c = *cfg;
     if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
-        !c.bitmap || !c.terms || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
+        !c.bitmap || !c.terms || !c.ebuf || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
     if (c.K > 1 && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
@@ -846,6 +906,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     lgcn_ctx *x = new (std::nothrow) lgcn_ctx;
     if (!x) { lgcn_set_error("out of memory"); return 4; }
     x->c = c; x->step = 0; x->N = c.graph->n_rows;
+    x->bm_words = (x->N + 31) / 32; x->flip = 0;
     const size_t stride = (size_t)x->N * c.d * esize(c.act_dtype);
     for (int k = 0; k < LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
     for (int k = 1; k < c.K; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
@@ -859,7 +920,8 @@ extern "C" void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr) { if (ctx) ctx->c.lr =
 
 static SpmmArgs base_spmm(const lgcn_ctx *x) {
     SpmmArgs a = graph_spmm(x->c.graph);
-    a.G64 = (const long long *)x->c.G64; a.bitmap = x->c.bitmap; a.div = (float)(x->c.K + 1); a.remap = x->c.xcd_remap;
+    a.G64 = (long long *)x->c.G64; a.bitmap = x->c.bitmap + x->flip * x->bm_words;
+    a.div = (float)(x->c.K + 1); a.remap = x->c.xcd_remap;
     return a;
 }
 
@@ -887,11 +949,16 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.users = users + b_off; a.pos = pos + b_off; a.neg = neg + b_off;
     a.B_local = B_local; a.shard = shard;
     a.inv_B = 1.0f / (float)B_global; a.lam = c.decay / (float)B_global;
-    a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = c.bitmap; a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
+    a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = c.bitmap + x->flip * x->bm_words;
+    a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
+    a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
+    a.ebuf = c.ebuf;
     if (B_local <= 0) return 0;
     DISPATCH_D(c.d, {
-        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_bpr<D, float>), dim3(B_local), dim3(192 * BPR_BW), 0, st, a);
-        else hipLaunchKernelGGL((k_bpr<D, bf16_t>), dim3(B_local), dim3(192 * BPR_BW), 0, st, a);
+        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
+        const int tpb = 256 / (D < 64 ? D : 64);
+        hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
     });
     return 0;
 }
@@ -902,7 +969,7 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
     const lgcn_train_config &c = x->c;
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
-    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap; s.gathered = gathered; s.shard = shard; s.world = world;
+    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
     s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
     const int spb = 256 / (c.d / 4);
     const unsigned sgrid = (unsigned)((3 * (int64_t)B + spb - 1) / spb);
@@ -926,6 +993,10 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
             a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
             a.step_size = (float)(c.lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
             a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
+            if (!first) {       // K >= 2: this launch also cleans the workspace and reduces the loss
+                a.clear = 1; a.terms = c.terms; a.gathered = gathered; a.loss_out = loss_out;
+                a.B = B; a.shard = shard; a.decay = c.decay;
+            }
         }
         int rc;
         if (first && last) rc = launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
@@ -935,6 +1006,7 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         if (rc) return rc;
         prev = y; prev_dt = c.act_dtype;
     }
+    if (c.K >= 2) { x->flip ^= 1; return 0; }       // next step flags rows in the other bitmap
     DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(sgrid), dim3(256), 0, st, s));
     return 0;
 }

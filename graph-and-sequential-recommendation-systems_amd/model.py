@@ -190,8 +190,9 @@ class LightGCN(nn.Module):
             st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
         st['act'] = torch.zeros(max(1, K - 1), N, d, dtype=tdt, device=dev)
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
-        st['bitmap'] = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
+        st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
         st['terms'] = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
+        st['ebuf'] = torch.zeros(3 * max_batch * d, dtype=torch.float32, device=dev)
         shard = (max_batch + dp_world - 1) // dp_world
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -202,6 +203,7 @@ class LightGCN(nn.Module):
         cfg.E0, cfg.adam_m, cfg.adam_v = self._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
         cfg.act, cfg.G64 = st['act'].data_ptr(), st['G64'].data_ptr()
         cfg.bitmap, cfg.terms, cfg.contrib = st['bitmap'].data_ptr(), st['terms'].data_ptr(), st['contrib'].data_ptr()
+        cfg.ebuf = st['ebuf'].data_ptr()
         cfg.err, cfg.max_batch = st['err'].data_ptr(), max_batch
         cfg.decay = float(self.config.get('decay', 1e-4))
         cfg.lr = float(self.config.get('lr', 1e-3))
