@@ -47,7 +47,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __bf16 bf16_t;
 
 #ifndef LGCN_GATHER_U
-#define LGCN_GATHER_U 8      /* row gathers in flight per lane */
+#define LGCN_GATHER_U 4      /* max row gathers in flight per lane (8 needs > 64 VGPRs: fewer resident waves, slower) */
 #endif
 #define FIXED_SCALE 1125899906842624.0   /* 2^50 */
 #define FIXED_INV   8.8817841970012523e-16 /* 2^-50 */
@@ -177,6 +177,9 @@ __device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt,
 template <int D, typename TI, bool SPARSE>
 __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
     constexpr int NPW = 64 / (D / 4), UMAX = SPARSE ? 2 : LGCN_GATHER_U;
+#ifdef LGCN_EXP_NO_GATHER
+    return;
+#endif
     cnt = __builtin_amdgcn_readfirstlane(cnt);
     int j = 0;
     if (UMAX >= 8) for (; cnt - j > 4 * NPW; j += 8 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 8 ? 8 : UMAX)>(stage, j, cnt, src, lane, acc);
@@ -315,8 +318,11 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 // Y = [Gs +] A_hat X.  256-thread workgroups = 4 waves.  Blocks [0, chunk_blocks) run one
 // long-row chunk per wave, the remaining blocks one short row per wave.
 //   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
+#ifndef SPMM_MIN_WAVES
+#define SPMM_MIN_WAVES 8      /* waves per SIMD the register allocation must allow (<= 64 VGPRs) */
+#endif
 template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(256) k_spmm(SpmmArgs a) {
+__global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr int LPR = D / 4;
     __shared__ int2 stage_lds[4][64];
     const int lane = threadIdx.x & 63;
