@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--xcd_remap", type=int, default=1)
     ap.add_argument("--row_order", default="cocluster", choices=["natural", "rcm", "cocluster"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
     ap.add_argument("--force_dp", action="store_true", help="use the data-parallel step (RCCL all-gather) even at world size 1")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
@@ -219,6 +220,21 @@ def main():
             "step_roofline_frac": step_bytes(N, nnz, d, s, K, B) * steps_per_sec / (HBM_PEAK_GBS * 1e9),
         }
 
+    # ---- the same workload with the other activation storage type (single GPU; reported, not the headline)
+    if rank == 0 and not use_dp and not a.no_secondary:
+        other = "bf16" if a.act_dtype == "fp32" else "fp32"
+        cfg2 = dict(w.config); cfg2['act_dtype'] = other
+        with contextlib.redirect_stdout(io.StringIO()):
+            pkg.utils.set_seed(2020)
+            model2 = pkg.model.LightGCN(cfg2, ds).to(dev)
+        model2.fused_epoch(users[:a.warmup * B], pos[:a.warmup * B], neg[:a.warmup * B], B)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        model2.fused_epoch(users[a.warmup * B:(a.warmup + a.steps) * B], pos[a.warmup * B:(a.warmup + a.steps) * B],
+                           neg[a.warmup * B:(a.warmup + a.steps) * B], B)
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+        out["config"][f"{other}_activation_storage_steps_per_sec"] = a.steps / dt2
+        del model2
+
     # ---- dominant kernel (dense CSR-SpMM layer) timed live with HIP events on the launch stream
     if rank == 0:
         L = pkg._lib
@@ -273,7 +289,7 @@ def main():
             tr.stageOne(hu[lo:lo + B], hp[lo:lo + B], hn[lo:lo + B])
             n_cpu += 1
         dt_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": n_cpu / dt_cpu, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": n_cpu / dt_cpu, "unit": "steps/s", "cores": orc.num_threads(), "kind": "port",
                                "sample": f"{n_cpu} consecutive stageOne steps of the same workload (same graph, same "
                                          f"triplets, B={B}) through oracle/lgcn_oracle.c (C + OpenMP, fp32), "
                                          f"{dt_cpu:.1f} s; the reference's own torch-CPU path measured 1.45-2.22 "

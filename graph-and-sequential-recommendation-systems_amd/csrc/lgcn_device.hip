@@ -245,7 +245,7 @@ struct LongPlan {
 
 struct SpmmArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
-    const int32_t *order;         // processing order of the rows (a permutation), or null = natural
+    const int4 *rowinfo;          // per position of the processing order: (row, first nnz, nnz count, 0)
     LongPlan lp;
     const void *X; void *Y;
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
@@ -383,11 +383,12 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     if (tile >= ntiles) return;
     const int64_t pos0 = (tile * 4 + wid) * SPMM_RW;
     if (pos0 >= a.n_rows) return;
-    // lane r < SPMM_RW fetches row id and both row pointers of its row; then wave-uniform registers
+    // lane r < SPMM_RW fetches (row id, first nnz, count) of its row with ONE 16-byte load from the
+    // plan (order -> indptr would be two dependent round trips); then wave-uniform registers
     int my_row = -1, my_s = 0, my_e = 0;
     if (lane < SPMM_RW && pos0 + lane < a.n_rows) {
-        my_row = a.order ? a.order[pos0 + lane] : (int)(pos0 + lane);
-        my_s = a.indptr[my_row]; my_e = a.indptr[my_row + 1];
+        const int4 ri = a.rowinfo[pos0 + lane];
+        my_row = ri.x; my_s = ri.y; my_e = ri.y + ri.z;
     }
     int rows[SPMM_RW], ip_s[SPMM_RW], ip_e[SPMM_RW];
 #pragma unroll
@@ -758,7 +759,7 @@ extern "C" int lgcn_device_available(void) {
 // graph object: device CSR (borrowed) + the long-row plan and its scratch (owned)
 // ---------------------------------------------------------------------------------
 struct lgcn_graph {
-    const int32_t *indptr; const int32_t *indices; const float *vals; const int32_t *order;
+    const int32_t *indptr; const int32_t *indices; const float *vals; const int4 *rowinfo;
     int64_t n_rows, nnz;
     int32_t d_max;
     LongPlan lp;
@@ -774,8 +775,9 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     std::vector<int32_t> ip((size_t)n_rows + 1);
     HIP_OK(hipMemcpy(ip.data(), indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost));
     if (ip[0] != 0 || (int64_t)ip[(size_t)n_rows] != nnz) { lgcn_set_error("lgcn_graph_create: indptr does not match nnz"); return 3; }
+    std::vector<int32_t> ord;
     if (row_order) {             // must be a permutation of 0..n_rows-1
-        std::vector<int32_t> ord((size_t)n_rows);
+        ord.resize((size_t)n_rows);
         HIP_OK(hipMemcpy(ord.data(), row_order, sizeof(int32_t) * ord.size(), hipMemcpyDeviceToHost));
         std::vector<char> seen((size_t)n_rows, 0);
         for (int64_t i = 0; i < n_rows; i++) {
@@ -795,28 +797,38 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             chunk_ptr.push_back(chunk_ptr.back() + nch);
         }
     }
+    std::vector<int32_t> rowinfo((size_t)n_rows * 4);
+    for (int64_t p = 0; p < n_rows; p++) {
+        const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
+        rowinfo[(size_t)p * 4 + 0] = r; rowinfo[(size_t)p * 4 + 1] = ip[(size_t)r];
+        rowinfo[(size_t)p * 4 + 2] = ip[(size_t)r + 1] - ip[(size_t)r]; rowinfo[(size_t)p * 4 + 3] = 0;
+    }
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
-    g->indptr = indptr; g->indices = indices; g->vals = vals; g->order = row_order;
+    g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr;
     g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
     g->owned = nullptr; g->lp = LongPlan{};
     const size_t n_long = long_row.size(), n_chunks = owner.size();
-    if (n_long) {
+    {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t o_row = 0, o_ptr = up(o_row + 4 * n_long), o_own = up(o_ptr + 4 * (n_long + 1)),
-                     o_cnt = up(o_own + 4 * n_chunks), o_par = up(o_cnt + 4 * n_long),
-                     total = o_par + n_chunks * (size_t)d_max * 4;
+        const size_t o_info = 0, o_row = up(o_info + 16 * (size_t)n_rows), o_ptr = up(o_row + 4 * n_long),
+                     o_own = up(o_ptr + 4 * (n_long + 1)), o_cnt = up(o_own + 4 * n_chunks),
+                     o_par = up(o_cnt + 4 * n_long), total = o_par + n_chunks * (size_t)d_max * 4 + 256;
         char *base = nullptr;
         if (hipMalloc((void **)&base, total) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
         g->owned = base;
         HIP_OK(hipMemset(base, 0, total));
-        HIP_OK(hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice));
-        g->lp.long_row = (const int32_t *)(base + o_row); g->lp.chunk_ptr = (const int32_t *)(base + o_ptr);
-        g->lp.chunk_owner = (const int32_t *)(base + o_own); g->lp.counters = (int32_t *)(base + o_cnt);
-        g->lp.partials = (float *)(base + o_par);
-        g->lp.n_long = (int32_t)n_long; g->lp.n_chunks = (int32_t)n_chunks;
+        HIP_OK(hipMemcpy(base + o_info, rowinfo.data(), 16 * (size_t)n_rows, hipMemcpyHostToDevice));
+        g->rowinfo = (const int4 *)(base + o_info);
+        if (n_long) {
+            HIP_OK(hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice));
+            g->lp.long_row = (const int32_t *)(base + o_row); g->lp.chunk_ptr = (const int32_t *)(base + o_ptr);
+            g->lp.chunk_owner = (const int32_t *)(base + o_own); g->lp.counters = (int32_t *)(base + o_cnt);
+            g->lp.partials = (float *)(base + o_par);
+            g->lp.n_long = (int32_t)n_long; g->lp.n_chunks = (int32_t)n_chunks;
+        }
     }
     *out = g;
     return 0;
@@ -830,7 +842,7 @@ extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
 
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.order = g->order; a.n_rows = g->n_rows; a.lp = g->lp;
+    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.rowinfo = g->rowinfo; a.n_rows = g->n_rows; a.lp = g->lp;
     return a;
 }
 

@@ -37,8 +37,10 @@ for e in range(1, a.epochs + 1):
     rt = ref["trajectory"][e - 1] if e <= len(ref["trajectory"]) else {}
     row = {"epoch": e, "info": info, "seconds": dt, "ref_avg_loss": rt.get("avg_loss"), "ref_steps": rt.get("steps")}
     if "test" in rt or e == a.epochs:
+        torch.cuda.synchronize(); t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             r = pkg.Procedure.Test(ds, model, e)
+        row["test_seconds"] = time.time() - t0
         row["test"] = {k: float(v[0]) for k, v in r.items()}
         if "test" in rt:
             row["ref_test"] = {k: v[0] for k, v in rt["test"].items()}
