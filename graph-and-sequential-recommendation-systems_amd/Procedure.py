@@ -40,19 +40,43 @@ def sample_epoch_to_device(dataset, device):
     return users, pos, neg
 
 
+_NEXT_EPOCH = {}          # id(dataset) -> (users, pos, neg, ready event): --prefetch_epoch 1
+
+
+def _prefetch_next_epoch(dataset):
+    """Sample + shuffle + upload the NEXT epoch on a side stream while the GPU still runs this one.
+    The sampler / shuffle streams do not depend on training, so the triplets are the same ones the
+    reference would draw at the start of the next epoch -- provided nothing else consumes the two
+    RNG streams in between (hence opt-in)."""
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        u, p, n = sample_epoch_to_device(dataset, world.device)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    _NEXT_EPOCH[id(dataset)] = (u, p, n, ev)
+
+
 def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=None):
     """Procedure.py:30-83."""
     Recmodel = recommend_model
     Recmodel.train()
     bpr = loss_class
     B = world.config['bpr_batch_size']
+    prefetch = bool(world.config.get('prefetch_epoch', 0)) and world.device.type == 'cuda'
 
     with timer(name="Sample"):
-        users, posItems, negItems = sample_epoch_to_device(dataset, world.device)
+        if prefetch and id(dataset) in _NEXT_EPOCH:
+            users, posItems, negItems, ev = _NEXT_EPOCH.pop(id(dataset))
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            users, posItems, negItems = sample_epoch_to_device(dataset, world.device)
 
     total_batch = len(users) // B + 1
     lr = bpr.opt.param_groups[0]['lr']
     losses = Recmodel.fused_epoch(users, posItems, negItems, B, lr=lr)     # [steps,3] on device
+    if prefetch:
+        with timer(name="Sample"):
+            _prefetch_next_epoch(dataset)                                   # host work under the GPU's epoch
     step_losses = losses[:, 0].double().cpu().numpy()                      # the epoch's only sync
     Recmodel.check_device_errors()
     aver_loss = float(step_losses.sum())

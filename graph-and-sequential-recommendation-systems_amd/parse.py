@@ -64,6 +64,8 @@ def build_parser():
                    help='NEW: give every XCD a contiguous range of graph rows')
     p.add_argument('--row_order', type=str, default='cocluster', choices=['natural', 'rcm', 'cocluster'],
                    help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
+    p.add_argument('--prefetch_epoch', type=int, default=0,
+                   help='NEW: 1 = sample/shuffle/upload epoch e+1 while epoch e runs on the GPU')
     p.add_argument('--data_path', type=str, default=None,
                    help='NEW: directory that holds <dataset>/train.txt (default: <root>/data)')
     return p

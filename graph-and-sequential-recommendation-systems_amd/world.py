@@ -98,6 +98,7 @@ def configure(argv=None):
     config['act_dtype'] = args.act_dtype
     config['xcd_remap'] = args.xcd_remap
     config['row_order'] = args.row_order
+    config['prefetch_epoch'] = args.prefetch_epoch
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

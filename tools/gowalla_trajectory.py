@@ -12,12 +12,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--epochs", type=int, default=10)
 ap.add_argument("--act_dtype", default="fp32")
 ap.add_argument("--out", default=None)
+ap.add_argument("--prefetch_epoch", type=int, default=0)
 a = ap.parse_args()
 sys.argv = [sys.argv[0]]
 import torch
 pkg = importlib.import_module("graph-and-sequential-recommendation-systems_amd")
 w = pkg.world
-w.configure(["--dataset", "gowalla", "--tensorboard", "0", "--act_dtype", a.act_dtype,
+w.configure(["--dataset", "gowalla", "--tensorboard", "0", "--act_dtype", a.act_dtype, "--prefetch_epoch", str(a.prefetch_epoch),
              "--checkpoint_dir", "/tmp/lgcn_traj_ckpt"])
 d = materialize_gowalla(GOWALLA_NPZ, "/tmp/lgcn_traj_gowalla")
 ref = json.load(open(os.path.join(REPO, "tests", "golden", "gowalla", "golden_long.json")))
