@@ -204,7 +204,7 @@ def main():
         s = 4 if a.act_dtype == "fp32" else 2
         steps_per_sec = a.steps / dt
         out = {
-            "metric": "BPR training steps/sec (one step = K-layer LightGCN propagation + BPR loss + backward + Adam on a batch of 2048 triplets per GPU)",
+            "metric": f"BPR training steps/sec (one step = K-layer LightGCN propagation + BPR loss + backward + Adam on a batch of {B} triplets per GPU)",
             "value": steps_per_sec * world, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.act_dtype == "fp32" else "f32 accumulate, bf16 activation storage",

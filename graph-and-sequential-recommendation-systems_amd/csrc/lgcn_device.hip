@@ -402,7 +402,11 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         const int deg = ip_e[0] - ip_s[0];
         if (!(split && deg > LONG_T) && lane < deg) { col_n = a.indices[ip_s[0] + lane]; val_n = a.vals[ip_s[0] + lane]; }
     }
-    f32x4 out[SPMM_RW];
+    // Results are flushed every NPW rows: group g finishes row q+g, so an epilogue pass keeps all 64
+    // lanes busy (epilogue after every single row made the next row's staging wait for the store).
+    constexpr int NPW = 64 / LPR;
+    const int g = lane / LPR, l = lane % LPR;
+    f32x4 out[NPW];
     unsigned live_mask = 0;
 #pragma unroll
     for (int r = 0; r < SPMM_RW; r++) {
@@ -421,20 +425,16 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
             live_mask |= 1u << r;
         }
         __builtin_amdgcn_wave_barrier();
-        out[r] = reduce_groups<D>(acc);
-    }
-    // Epilogues last (a store between rows makes the next row's staging wait for it): group g
-    // finishes row q+g, all 64 lanes busy.
-    constexpr int NPW = 64 / LPR;
-    const int g = lane / LPR, l = lane % LPR;
+        out[r % NPW] = reduce_groups<D>(acc);
+        if (r % NPW == NPW - 1 || r == SPMM_RW - 1) {
+            const int q = r - (r % NPW);
+            f32x4 mine = out[0];
+            int mrow = rows[q];
 #pragma unroll
-    for (int q = 0; q < SPMM_RW; q += NPW) {
-        f32x4 mine = out[q];
-        int mrow = rows[q];
-#pragma unroll
-        for (int t = 1; t < NPW; t++) if (q + t < SPMM_RW && g == t) { mine = out[q + t]; mrow = rows[q + t]; }
-        const int r = q + g;
-        if (r < SPMM_RW && ((live_mask >> r) & 1u)) spmm_epilogue<D, TO, MODE>(a, mrow, l, mine);
+            for (int t = 1; t < NPW; t++) if (q + t <= r && g == t) { mine = out[t]; mrow = rows[q + t]; }
+            const int rr = q + g;
+            if (rr <= r && ((live_mask >> rr) & 1u)) spmm_epilogue<D, TO, MODE>(a, mrow, l, mine);
+        }
     }
 }
 
@@ -817,13 +817,16 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         char *base = nullptr;
         if (hipMalloc((void **)&base, total) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
         g->owned = base;
-        HIP_OK(hipMemset(base, 0, total));
-        HIP_OK(hipMemcpy(base + o_info, rowinfo.data(), 16 * (size_t)n_rows, hipMemcpyHostToDevice));
+        hipError_t e1 = hipMemset(base, 0, total);
+        if (e1 == hipSuccess) e1 = hipMemcpy(base + o_info, rowinfo.data(), 16 * (size_t)n_rows, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess && n_long) {
+            e1 = hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice);
+        }
+        if (e1 != hipSuccess) { (void)hipFree(base); delete g; lgcn_set_error("lgcn_graph_create: plan upload failed"); return 10; }
         g->rowinfo = (const int4 *)(base + o_info);
         if (n_long) {
-            HIP_OK(hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice));
             g->lp.long_row = (const int32_t *)(base + o_row); g->lp.chunk_ptr = (const int32_t *)(base + o_ptr);
             g->lp.chunk_owner = (const int32_t *)(base + o_own); g->lp.counters = (int32_t *)(base + o_cnt);
             g->lp.partials = (float *)(base + o_par);

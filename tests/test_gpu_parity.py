@@ -435,3 +435,36 @@ def test_fused_steps_other_dims_vs_oracle(pkg, oracle, tmp_path, d, K, act):
     np.testing.assert_allclose(torch.cat([au, ai]).cpu().numpy(), ref, rtol=2e-5 if act == "fp32" else 3e-2,
                                atol=2e-6 if act == "fp32" else 3e-3)
     m.check_device_errors()
+
+
+def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
+    """Checkpoint surface of main.py:56-87: model.state_dict() (keys embedding_user/item.weight) +
+    bpr.opt.state_dict() (torch-Adam format: step / exp_avg / exp_avg_sq) saved after 2 steps,
+    loaded into a fresh model, third step bitwise equal to the uninterrupted run."""
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(9))
+    batches = [tuple(_dev(rng.integers(0, hi, 64), torch.int32) for hi in (g.n_users, g.m_items, g.m_items)) for _ in range(3)]
+    ds, m = _make_model(pkg, g, tmp_path)
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    for b in batches[:2]:
+        bpr.stageOne(*b)
+    ckpt = os.path.join(str(tmp_path), "last.pth.tar")
+    torch.save({'epoch': 1, 'model_state': m.state_dict(), 'optimizer_state': bpr.opt.state_dict()}, ckpt + ".tmp")
+    os.replace(ckpt + ".tmp", ckpt)
+    l3 = bpr.stageOne(*batches[2])
+    want = m._table.cpu().numpy().copy()
+    sd = torch.load(ckpt, weights_only=True)
+    assert list(sd['model_state'].keys()) == ['embedding_user.weight', 'embedding_item.weight']
+    st = sd['optimizer_state']['state']
+    assert int(st[0]['step']) == 2 and st[0]['exp_avg'].shape == (g.n_users, g.d) and st[1]['exp_avg_sq'].shape == (g.m_items, g.d)
+    ds2, m2 = _make_model(pkg, g, tmp_path)
+    bpr2 = pkg.utils.BPRLoss(m2, pkg.world.config)
+    m2.load_state_dict(sd['model_state'])
+    bpr2.opt.load_state_dict(sd['optimizer_state'])
+    assert m2.adam_step == 2
+    l3b = bpr2.stageOne(*batches[2])
+    assert l3 == l3b and np.array_equal(m2._table.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # a plain torch Adam can read the same state (interchange with the reference's optimizer)
+    ref_opt = torch.optim.Adam(m2.parameters(), lr=pkg.world.config['lr'])
+    ref_opt.load_state_dict(bpr2.opt.state_dict())
+    assert int(ref_opt.state_dict()['state'][0]['step']) == 3
