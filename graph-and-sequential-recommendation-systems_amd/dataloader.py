@@ -20,25 +20,20 @@ from .world import cprint
 
 
 class BasicDataset(Dataset):
-    """Protocol of dataloader.py:26-48."""
+    """The dataset protocol of dataloader.py:26-48: five read-only attributes and three
+    methods that every concrete dataset provides."""
 
-    def __init__(self):
-        pass
+    def _missing(self, *_a, **_k):
+        raise NotImplementedError
 
-    @property
-    def n_users(self): raise NotImplementedError
-    @property
-    def m_items(self): raise NotImplementedError
-    @property
-    def trainDataSize(self): raise NotImplementedError
-    @property
-    def testDict(self): raise NotImplementedError
-    @property
-    def allPos(self): raise NotImplementedError
-
-    def getUserItemFeedback(self, users, items): raise NotImplementedError
-    def getUserPosItems(self, users): raise NotImplementedError
-    def getSparseGraph(self): raise NotImplementedError
+    n_users = property(_missing)
+    m_items = property(_missing)
+    trainDataSize = property(_missing)
+    testDict = property(_missing)
+    allPos = property(_missing)
+    getUserItemFeedback = _missing
+    getUserPosItems = _missing
+    getSparseGraph = _missing
 
 
 def _read_interactions(path):
@@ -106,14 +101,10 @@ class Loader(BasicDataset):
         self.Graph = None
         self._norm_adj = None
 
-    @property
-    def n_users(self): return self.n_user
-    @property
-    def m_items(self): return self.m_item
-    @property
-    def trainDataSize(self): return self.traindataSize
-    @property
-    def testDict(self): return self.__testDict
+    n_users = property(lambda self: self.n_user)
+    m_items = property(lambda self: self.m_item)
+    trainDataSize = property(lambda self: self.traindataSize)
+    testDict = property(lambda self: self.__testDict)
 
     @property
     def allPos(self):
@@ -127,13 +118,11 @@ class Loader(BasicDataset):
         return self._r_indptr, self._r_indices
 
     def __build_test(self):
-        test_data = {}
+        """{user: [test items]} in file order (dataloader.py:165-171)."""
+        grouped = {}
         for u, i in zip(self.testUser.tolist(), self.testItem.tolist()):
-            if u in test_data:
-                test_data[u].append(i)
-            else:
-                test_data[u] = [i]
-        return test_data
+            grouped.setdefault(u, []).append(i)
+        return grouped
 
     def getUserItemFeedback(self, users, items):
         return np.array(self.UserItemNet[users, items]).astype('uint8').reshape((-1,))
@@ -144,22 +133,17 @@ class Loader(BasicDataset):
 
     # ---------- adjacency ----------
     def _convert_sp_mat_to_sp_tensor(self, X):
-        coo = X.tocoo().astype(np.float32)
-        row = torch.from_numpy(coo.row).long()
-        col = torch.from_numpy(coo.col).long()
-        index = torch.stack([row, col], dim=0)
-        data = torch.from_numpy(coo.data).float()
-        return torch.sparse_coo_tensor(index, data, torch.Size(coo.shape))
+        """scipy sparse -> torch sparse COO, fp32 values / int64 indices (dataloader.py:183-190)."""
+        m = X.tocoo()
+        ij = torch.from_numpy(np.vstack([m.row, m.col]).astype(np.int64))
+        return torch.sparse_coo_tensor(ij, torch.from_numpy(m.data.astype(np.float32)), torch.Size(m.shape))
 
     def _split_A_hat(self, A):
-        A_fold = []
+        """`A_n_fold` row blocks of A_hat, the last one taking the remainder (dataloader.py:192-201)."""
         n_all = self.n_users + self.m_items
-        fold_len = n_all // self.folds
-        for i_fold in range(self.folds):
-            start = i_fold * fold_len
-            end = n_all if i_fold == self.folds - 1 else (i_fold + 1) * fold_len
-            A_fold.append(self._convert_sp_mat_to_sp_tensor(A[start:end]).coalesce().to(world.device))
-        return A_fold
+        step = n_all // self.folds
+        bounds = [(k * step, n_all if k == self.folds - 1 else (k + 1) * step) for k in range(self.folds)]
+        return [self._convert_sp_mat_to_sp_tensor(A[lo:hi]).coalesce().to(world.device) for lo, hi in bounds]
 
     def _build_norm_adj(self):
         """dataloader.py:218-234 through the native builder."""

@@ -1,28 +1,21 @@
-"""Dataset & model registry, mirror of the reference's register.py (register.py:16-55).
-Importing it instantiates `dataset = Loader(world.config)` like the reference."""
+"""Dataset and model registry -- the role of the reference's register.py (register.py:16-55):
+importing this module builds `dataset` from world.config and exposes MODELS[name] -> class."""
+from . import model as _model
 from . import world
-from . import model
-from .world import cprint  # noqa: F401
 from .dataloader import Loader
+from .world import cprint  # noqa: F401  (re-exported like the reference does)
 
-print("comment:", world.comment)
-print("tensorboard:", world.tensorboard)
-print("LOAD:", world.LOAD)
-print("Weight path:", world.PATH)
+for _label, _value in (("comment", world.comment), ("tensorboard", world.tensorboard),
+                       ("LOAD", world.LOAD), ("Weight path", world.PATH)):
+    print(f"{_label}: {_value}")
 
+# Loader(config) is the constructor of this package; forks that read world.config themselves take no argument
 try:
     dataset = Loader(world.config)
 except TypeError:
     dataset = Loader()
 
-MODELS = {}
-if hasattr(model, 'PureMF'):
-    MODELS['mf'] = model.PureMF
-if hasattr(model, 'LightGCN'):
-    MODELS['lgn'] = model.LightGCN
+MODELS = {key: getattr(_model, cls) for key, cls in (("mf", "PureMF"), ("lgn", "LightGCN")) if hasattr(_model, cls)}
 
 if world.model_name not in MODELS:
-    raise ValueError(
-        f"Requested model '{world.model_name}' is not available. "
-        f"Available models: {list(MODELS.keys())}. "
-        f"Ensure model.py defines the class, or run with --model one of {list(MODELS.keys())}.")
+    raise ValueError(f"model '{world.model_name}' is not registered; choose one of {sorted(MODELS)} with --model")

@@ -144,19 +144,22 @@ def set_seed(seed):
 
 
 def getFileName():
-    """utils.py:123-132."""
-    if world.model_name == 'mf':
-        file = f"mf-{world.dataset}-{world.config['latent_dim_rec']}.pth.tar"
-    elif world.model_name == 'lgn':
-        file = f"lgn-{world.dataset}-{world.config['lightGCN_n_layers']}-{world.config['latent_dim_rec']}.pth.tar"
-    return os.path.join(world.PATH, file)
+    """Legacy weight file name lgn-<dataset>-<layers>-<dim>.pth.tar / mf-<dataset>-<dim>.pth.tar (utils.py:123-132)."""
+    dim = world.config['latent_dim_rec']
+    stem = {'mf': f"mf-{world.dataset}-{dim}",
+            'lgn': f"lgn-{world.dataset}-{world.config['lightGCN_n_layers']}-{dim}"}[world.model_name]
+    return os.path.join(world.PATH, stem + ".pth.tar")
 
 
 def minibatch(*tensors, **kwargs):
-    """utils.py:135-139 (always yields a tuple, like the fork)."""
-    batch_size = kwargs.get('batch_size', world.config['bpr_batch_size'])
-    for i in range(0, len(tensors[0]), batch_size):
-        yield tuple(x[i:i + batch_size] for x in tensors)
+    """Consecutive slices of `batch_size` rows of every input, last one short; always a tuple, like the
+    fork (utils.py:135-139)."""
+    size = kwargs.get('batch_size', world.config['bpr_batch_size'])
+    total = len(tensors[0])
+    start = 0
+    while start < total:
+        yield tuple(t[start:start + size] for t in tensors)
+        start += size
 
 
 def shuffle_indices(n):
@@ -225,30 +228,30 @@ class timer:
 
 
 # ==================== Evaluation Metrics (utils.py:173-217) ====================
+def _discounts(k):
+    return 1.0 / np.log2(np.arange(2, k + 2))
+
+
 def RecallPrecision_ATk(test_data, r, k):
-    right_pred = r[:, :k].sum(1)
-    precis_n = k
-    recall_n = np.array([len(test_data[i]) for i in range(len(test_data))])
-    recall = np.sum(right_pred / recall_n)
-    precis = np.sum(right_pred) / precis_n
-    return {'recall': recall, 'precision': precis}
+    """Sums over the batch of recall@k (hits / |ground truth|) and precision@k (hits / k)."""
+    hits = r[:, :k].sum(1)
+    gt_sizes = np.fromiter((len(t) for t in test_data), dtype=np.int64, count=len(test_data))
+    return {'recall': np.sum(hits / gt_sizes), 'precision': np.sum(hits) / k}
 
 
 def NDCGatK_r(test_data, r, k):
+    """Sum over the batch of DCG@k / IDCG@k, IDCG from min(k, |ground truth|) leading ones."""
     assert len(r) == len(test_data)
-    pred_data = r[:, :k]
-    test_matrix = np.zeros((len(pred_data), k))
-    for i, items in enumerate(test_data):
-        test_matrix[i, :min(k, len(items))] = 1
-    idcg = np.sum(test_matrix * 1. / np.log2(np.arange(2, k + 2)), axis=1)
-    dcg = np.sum(pred_data * (1. / np.log2(np.arange(2, k + 2))), axis=1)
+    disc = _discounts(k)
+    ideal = np.zeros((len(test_data), k))
+    for row, items in zip(ideal, test_data):
+        row[:min(k, len(items))] = 1
+    idcg = (ideal * disc).sum(axis=1)
     idcg[idcg == 0.] = 1.
-    ndcg = dcg / idcg
-    return np.sum(ndcg)
+    return np.sum((r[:, :k] * disc).sum(axis=1) / idcg)
 
 
 def getLabel(groundTruth, predictTopK):
-    if not isinstance(groundTruth, (list, set, tuple, np.ndarray)):
-        groundTruth = [groundTruth]
-    pred = [1.0 if x in groundTruth else 0.0 for x in predictTopK]
-    return np.array(pred, dtype=np.float32)
+    """0/1 float32 vector: is the j-th predicted item in the ground truth?"""
+    truth = groundTruth if isinstance(groundTruth, (list, set, tuple, np.ndarray)) else [groundTruth]
+    return np.fromiter((1.0 if x in truth else 0.0 for x in predictTopK), dtype=np.float32, count=len(predictTopK))
