@@ -438,36 +438,23 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     }
 }
 
-// out = (X_0 + X_1 + ... + X_{K-1} + A X_{K-1}) / (K+1)   -- last layer of computer()
+// out = (X_0 + X_1 + ... + X_{K-1} + out) / (K+1), `out` holding X_K on entry -- the stack + mean of
+// computer() (model.py:221-222) as one streaming pass.  The K-th layer itself runs through k_spmm
+// like the others, so evaluation gets the split long rows too.
 struct MeanArgs {
-    const int32_t *indptr; const int32_t *indices; const float *vals;
     const float *X0; const void *Xl[LGCN_MAX_LAYERS]; int K;
-    float *out; int64_t n_rows; int remap;
+    float *out; int64_t n4;      // number of 4-element pieces
 };
 
-template <int D, typename TI>
-__global__ void __launch_bounds__(256) k_spmm_mean(MeanArgs a) {
-    constexpr int LPR = D / 4;
-    __shared__ int2 stage_lds[4][64];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t ntiles = (a.n_rows + 3) >> 2;
-    const int64_t tile = tile_of_block(blockIdx.x, ntiles, a.remap);
-    if (tile >= ntiles) return;
-    const int64_t row = tile * 4 + wid;
-    if (row >= a.n_rows) return;
-    const int start = a.indptr[row], end = a.indptr[row + 1];
-    GatherSrc src; src.bm = nullptr; src.div = 1.f;
-    f32x4 xk;
-    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, start, end, src, lane, stage_lds[wid]); }
-    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, start, end, src, lane, stage_lds[wid]); }
-    if (lane >= LPR) return;
-    const int64_t off = row * D + lane * 4;
-    f32x4 s = load4(a.X0 + off);
-    for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + off);
-    s += xk;
+template <typename TI>
+__global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
     const float div = (float)(a.K + 1);
-    store4(a.out + off, s / div);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = load4(a.X0 + i * 4);
+        for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + i * 4);
+        s += load4(a.out + i * 4);
+        store4(a.out + i * 4, s / div);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -698,12 +685,6 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
-static inline unsigned grid_rows(int64_t n_rows, int remap) {
-    int64_t ntiles = (n_rows + 3) / 4;
-    if (remap) ntiles = ((ntiles + 7) / 8) * 8;
-    return (unsigned)ntiles;
-}
-
 template <int D, typename TI, typename TO, int MODE>
 static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
@@ -872,21 +853,22 @@ extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = g->n_rows;
     MeanArgs m{};
-    m.indptr = g->indptr; m.indices = g->indices; m.vals = g->vals; m.X0 = E0; m.K = K; m.out = out; m.n_rows = N; m.remap = 1;
+    m.X0 = E0; m.K = K; m.out = out; m.n4 = N * d / 4;
     const size_t stride = (size_t)N * d * esize(act_dtype);
     const void *prev = E0; int prev_dtype = LGCN_F32;
-    for (int k = 1; k < K; k++) {
-        void *y = (char *)work + (size_t)(k - 1) * stride;
+    for (int k = 1; k <= K; k++) {
+        const bool last = (k == K);
+        void *y = last ? (void *)out : (void *)((char *)work + (size_t)(k - 1) * stride);
         SpmmArgs a = graph_spmm(g);
         a.X = prev; a.Y = y; a.remap = 1;
-        int rc = launch_spmm<0>(a, d, prev_dtype, act_dtype, st);
+        int rc = launch_spmm<0>(a, d, prev_dtype, last ? LGCN_F32 : act_dtype, st);
         if (rc) return rc;
-        m.Xl[k] = y; prev = y; prev_dtype = act_dtype;
+        if (!last) { m.Xl[k] = y; prev = y; prev_dtype = act_dtype; }
     }
-    DISPATCH_D(d, {
-        if (act_dtype == LGCN_F32) hipLaunchKernelGGL((k_spmm_mean<D, float>), dim3(grid_rows(N, 1)), dim3(256), 0, st, m);
-        else hipLaunchKernelGGL((k_spmm_mean<D, bf16_t>), dim3(grid_rows(N, 1)), dim3(256), 0, st, m);
-    });
+    const int64_t blocks = (m.n4 + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    if (act_dtype == LGCN_F32) hipLaunchKernelGGL((k_layer_mean<float>), dim3(grid), dim3(256), 0, st, m);
+    else hipLaunchKernelGGL((k_layer_mean<bf16_t>), dim3(grid), dim3(256), 0, st, m);
     HIP_OK(hipGetLastError());
     return 0;
 }
