@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--row_order", default="cocluster", choices=["natural", "rcm", "cocluster"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
+    ap.add_argument("--dp_reduce", default="rows", choices=["rows", "dense"],
+                    help="data-parallel gradient exchange: all-gather of gradient rows (default) or dense all-reduce")
     ap.add_argument("--force_dp", action="store_true", help="use the data-parallel step (RCCL all-gather) even at world size 1")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
@@ -170,7 +172,7 @@ def main():
         def run(lo, steps):
             return model.fused_epoch(users[lo:lo + steps * B], pos[lo:lo + steps * B], neg[lo:lo + steps * B], B)
     else:
-        dp = pkg.parallel.DataParallelBPR(model, w.config)
+        dp = pkg.parallel.DataParallelBPR(model, w.config, reduce=a.dp_reduce)
         dp.lazy = True
 
         def run(lo, steps):

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lgcn_train_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_train_epoch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
     "lgcn_train_step_dp_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "lgcn_train_step_dp_dense_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
 }

@@ -485,7 +485,8 @@ struct BprArgs {
     uint32_t *bitmap;
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
     float *contrib;       // else: [3*shard*D | shard | shard]
-    float *terms;         // single GPU: [2*B]  (loss terms, reg terms)
+    float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
+    int32_t terms_off, terms_stride;
     int32_t *err;
 };
 
@@ -578,8 +579,8 @@ __global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
     const float x = ps - ns;
     const float gb = tbad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
     if (l == 0) {
-        float *lt = a.G64 ? a.terms : a.contrib + (int64_t)3 * a.shard * D;
-        const int stride = a.G64 ? a.B_local : a.shard;
+        float *lt = a.G64 ? a.terms + a.terms_off : a.contrib + (int64_t)3 * a.shard * D;
+        const int stride = a.G64 ? a.terms_stride : a.shard;
         lt[b] = tbad ? 0.f : logsigmoid_f(x);
         lt[stride + b] = tbad ? 0.f : rr;
     }
@@ -631,6 +632,15 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     f32x4 g = load4(a.gathered + r * blk + ((int64_t)c * a.shard + i) * D + l * 4);
     atomic_add_fixed4(a.G64 + row * D + l * 4, g);
     if (l == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+}
+
+// dense data-parallel form: flag the rows of the WHOLE global batch (every rank knows all ids), so the
+// row bitmap needs no collective (RCCL has no bitwise-OR reduction)
+__global__ void __launch_bounds__(256) k_flag_rows(SlotArgs a) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= 3 * a.B) return;
+    const int64_t row = slot_row(s / a.B, s % a.B, a.users, a.pos, a.neg, a.n_users, a.N);
+    if (row >= 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
 }
 
 // End of step: zero what the step touched (G64 rows, bitmap words of the batch rows);
@@ -955,6 +965,7 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = c.bitmap + x->flip * x->bm_words;
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
+    a.terms_off = atomics ? b_off : 0; a.terms_stride = B_global;
     a.ebuf = c.ebuf;
     if (B_local <= 0) return 0;
     DISPATCH_D(c.d, {
@@ -1063,12 +1074,35 @@ extern "C" int lgcn_train_step_dp_part1(lgcn_ctx *x, const int32_t *users, const
     return 0;
 }
 
+extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                                              int32_t B_global, int32_t world, int32_t rank, void *stream) {
+    int rc = check_batch(x, users, pos, neg, B_global);
+    if (rc) return rc;
+    if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("dp step: bad world/rank"); return 3; }
+    const int32_t shard = (B_global + world - 1) / world;
+    const int32_t b_off = rank * shard;
+    int32_t B_local = B_global - b_off;
+    if (B_local > shard) B_local = shard;
+    if (B_local < 0) B_local = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // this rank owns positions [b_off, b_off+B_local) of the global loss-term arrays; the rest must be zero
+    HIP_OK(hipMemsetAsync(x->c.terms, 0, sizeof(float) * 2 * (size_t)B_global, st));
+    if ((rc = run_forward(x, st))) return rc;
+    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, st))) return rc;
+    SlotArgs s{};
+    s.users = users; s.pos = pos; s.neg = neg; s.B = B_global; s.n_users = x->c.n_users; s.N = x->N;
+    s.bitmap = x->c.bitmap + x->flip * x->bm_words;
+    hipLaunchKernelGGL(k_flag_rows, dim3((3 * B_global + 255) / 256), dim3(256), 0, st, s);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int lgcn_train_step_dp_part2(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
                                         int32_t B_global, int32_t world, const float *gathered, float *loss_out,
                                         void *stream) {
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
-    if (!gathered || !loss_out || world < 1) { lgcn_set_error("dp step part 2: invalid argument"); return 3; }
+    if (!loss_out || world < 1) { lgcn_set_error("dp step part 2: invalid argument"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
     if ((rc = run_backward(x, users, pos, neg, B_global, gathered, shard, world, loss_out, (hipStream_t)stream))) return rc;
     HIP_OK(hipGetLastError());

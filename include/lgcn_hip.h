@@ -184,6 +184,17 @@ int lgcn_train_epoch(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, co
 int lgcn_train_step_dp_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
                              const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
                              void *stream);
+/* The literal north_star form (dense gradient all-reduce), kept as an alternative:
+ *   dense part 1  forward + this rank's shard accumulated into ITS OWN G64 / bitmap / loss terms
+ *                 (1/B and decay/B of the global batch);
+ *   (caller: RCCL all-reduce SUM of G64 [N*d int64] and of terms [2*B_global fp32]; the row bitmap
+ *    is flagged for the whole global batch on every rank and needs no collective)
+ *   part 2 with gathered == NULL: backward + Adam from the reduced G64.
+ * Integer sums commute, so this is again bitwise equal to lgcn_train_step -- but it moves
+ * N*d*8 bytes per step (Gowalla 36 MB) instead of 1.6 MB.                                */
+int lgcn_train_step_dp_dense_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
+                                   const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
+                                   void *stream);
 int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
                              const int32_t *neg, int32_t B_global, int32_t world,
                              const float *gathered, float *loss_out, void *stream);

@@ -242,6 +242,28 @@ def test_bitwise_reproducible_and_dp_split(pkg, tiny, tmp_path):
             losses.append(out.cpu().numpy())
         return m._table.cpu().numpy().copy(), np.array(losses)
 
+    def run_dense(world):
+        """dense (all-reduce) form emulated on one GPU: every rank's part 1 accumulates into the same
+        G64 / bitmap / terms, which is exactly what the SUM / BOR all-reduces produce."""
+        ds, m = _make_model(pkg, g, tmp_path)
+        L, lib = pkg._lib, pkg._lib.load()
+        losses = []
+        for (u, p, n) in batches:
+            u, p, n = (_dev(x, torch.int32) for x in (u, p, n))
+            B = len(u)
+            st = m._state(max_batch=64, need_ctx=True, dp_world=world)
+            acc_terms = torch.zeros(2 * B, device=DEV)
+            for r in range(world):
+                L.check(lib.lgcn_train_step_dp_dense_part1(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, r,
+                                                           L.current_stream()), "dense part1")
+                acc_terms += st['terms'][:2 * B]
+            st['terms'][:2 * B].copy_(acc_terms)
+            out = torch.empty(3, device=DEV)
+            L.check(lib.lgcn_train_step_dp_part2(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, None,
+                                                 L.tp(out), L.current_stream()), "part2")
+            losses.append(out.cpu().numpy())
+        return m._table.cpu().numpy().copy(), np.array(losses)
+
     p1, l1 = run(1)
     p1b, l1b = run(1)
     assert np.array_equal(p1.view(np.uint32), p1b.view(np.uint32)) and np.array_equal(l1, l1b)
@@ -249,6 +271,9 @@ def test_bitwise_reproducible_and_dp_split(pkg, tiny, tmp_path):
         pw, lw = run(world)
         assert np.array_equal(p1.view(np.uint32), pw.view(np.uint32)), world
         np.testing.assert_allclose(lw, l1, rtol=0, atol=1e-6)
+        pd, ld = run_dense(world)
+        assert np.array_equal(p1.view(np.uint32), pd.view(np.uint32)), ("dense", world)
+        np.testing.assert_allclose(ld, l1, rtol=0, atol=1e-6)
 
 
 def test_out_of_range_ids_are_flagged_not_faulting(pkg, tiny, tmp_path):
