@@ -493,3 +493,30 @@ def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
     ref_opt = torch.optim.Adam(m2.parameters(), lr=pkg.world.config['lr'])
     ref_opt.load_state_dict(bpr2.opt.state_dict())
     assert int(ref_opt.state_dict()['state'][0]['step']) == 3
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_spmm_row_length_boundaries(pkg, oracle, d):
+    """Row lengths on both sides of every internal boundary of the SpMM kernel: the 64-entry index
+    tile (short-row path), the one-chunk rows (65..128) and the multi-chunk rows that go through
+    the partial-row hand-off (129, 256, 257, 1000), plus empty rows, in every position of the
+    4-rows-per-wave / 4-waves-per-workgroup tiling."""
+    rng = np.random.Generator(np.random.PCG64(100 + d))
+    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193,
+            255, 256, 257, 511, 1000, 0, 64, 65, 128, 129, 7, 7, 7]
+    n = 1200
+    deg = np.array([lens[i % len(lens)] for i in range(n)], np.int64)
+    deg = deg[rng.permutation(n)]
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in deg]).astype(np.int32)
+    vals = rng.uniform(0.01, 0.4, len(indices)).astype(np.float32)
+    X = rng.normal(0, 0.1, (n, d)).astype(np.float32)
+    ref = oracle.spmm(indptr, indices, vals, X)
+    for order in (None, rng.permutation(n).astype(np.int32)):
+        g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order)
+        got = g.spmm(_dev(X)).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+        again = g.spmm(_dev(X)).cpu().numpy()          # counters of the hand-off are reset: second launch identical
+        assert np.array_equal(got.view(np.uint32), again.view(np.uint32))
+        g.close()
+    assert np.array_equal(got[deg == 0], np.zeros_like(got[deg == 0]))

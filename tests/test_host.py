@@ -252,3 +252,49 @@ def test_row_orders_are_permutations(pkg, tiny, lastfm, tmp_path):
             assert np.array_equal(o, pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path))   # cached
     with pytest.raises(ValueError):
         pkg.reorder.row_order('bogus', ds, adj)
+
+
+def test_user_item_csr_matches_scipy_on_random_inputs(pkg):
+    """Native COO -> canonical CSR (sorted columns, duplicates summed) vs scipy, incl. duplicates,
+    empty users and the id range check."""
+    import scipy.sparse as sp
+    lib = pkg._lib.load()
+    rng = np.random.Generator(np.random.PCG64(42))
+    for n_users, m_items, E in ((1, 1, 1), (7, 5, 40), (300, 211, 5000), (50, 1000, 0)):
+        tu = rng.integers(0, n_users, E).astype(np.int64)
+        ti = rng.integers(0, m_items, E).astype(np.int64)
+        indptr = np.zeros(n_users + 1, np.int64); nnz = np.zeros(1, np.int64)
+        indices = np.empty(max(E, 1), np.int32); vals = np.empty(max(E, 1), np.float32)
+        rc = lib.lgcn_build_user_item_csr(n_users, m_items, E, pkg._lib.npp(tu), pkg._lib.npp(ti),
+                                          pkg._lib.npp(indptr), pkg._lib.npp(indices), pkg._lib.npp(vals), pkg._lib.npp(nnz))
+        assert rc == 0
+        R = sp.csr_matrix((np.ones(E, np.float32), (tu, ti)), shape=(n_users, m_items))
+        R.sum_duplicates(); R.sort_indices()
+        k = int(nnz[0])
+        assert k == R.nnz and np.array_equal(indptr, R.indptr)
+        assert np.array_equal(indices[:k], R.indices) and np.array_equal(vals[:k], R.data)
+    bad = np.array([0, 9], np.int64)
+    assert lib.lgcn_build_user_item_csr(5, 5, 2, pkg._lib.npp(bad), pkg._lib.npp(bad), pkg._lib.npp(np.zeros(6, np.int64)),
+                                        pkg._lib.npp(np.zeros(2, np.int32)), pkg._lib.npp(np.zeros(2, np.float32)),
+                                        pkg._lib.npp(np.zeros(1, np.int64))) == 3
+
+
+def test_sampler_invariants(pkg, tiny, tmp_path):
+    """Every triplet: positive is one of the user's train items, negative is not; cpp mode draws
+    trainDataSize//n_users triplets per user grouped by user."""
+    ds = _load(pkg, tiny, tmp_path)
+    pos_sets = [set(p.tolist()) for p in ds.allPos]
+    pkg.sampling.seed(99)
+    for neg_num in (1, 3):
+        S = pkg.sampling.sample_negative(ds.n_users, ds.m_items, ds.trainDataSize, ds.pos_csr(), neg_num)
+        per = ds.trainDataSize // ds.n_users
+        assert S.shape == (ds.n_users * per, 2 + neg_num)
+        assert np.array_equal(S[:, 0], np.repeat(np.arange(ds.n_users), per))
+        for row in S:
+            assert row[1] in pos_sets[row[0]] and all(x not in pos_sets[row[0]] for x in row[2:])
+            assert all(0 <= x < ds.m_items for x in row[1:])
+    pkg.utils.set_seed(5)
+    S = pkg.utils.UniformSample_original_python(ds)
+    assert len(S) == ds.trainDataSize
+    for u, p, n in S:
+        assert p in pos_sets[u] and n not in pos_sets[u]
