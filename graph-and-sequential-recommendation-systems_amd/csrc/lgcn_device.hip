@@ -222,18 +222,22 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t bid, int64_t ntiles, in
     return (bid & 7) * per + (bid >> 3);   // may be >= ntiles: caller checks
 }
 
-// Rows with more than LONG_T (= one 64-entry tile) non-zeros leave the short-row path.  They
-// are cut into chunks of LONG_CH non-zeros that run as independent waves in front of the
-// grid (a single wave walking Gowalla's 1415-nnz row = 23 serial tiles was the critical
-// path = the entire 57 us of the un-split launch).  A row of one chunk is finished by its
-// wave; otherwise each chunk writes a partial row and takes a ticket, and the LAST arriver
-// sums the partials in chunk order (fixed order: bitwise reproducible whoever is last)
-// and runs the epilogue.
+// Rows with more than LONG_T (= one 64-entry tile) non-zeros leave the short-row path and run as
+// independent waves at the FRONT of the grid (they start first, so their serial tile walk
+// overlaps everything else).  Rows up to LONG_CH non-zeros are finished by one wave.  Longer
+// rows are cut into chunks of LONG_CH (a single wave walking Gowalla's 1415-nnz row = 23
+// serial tiles was the critical path = the entire 57 us of the un-split launch): each chunk
+// writes a partial row and takes a ticket, and the LAST arriver sums the partials in chunk
+// order (fixed order: bitwise reproducible whoever is last) and runs the epilogue.  The
+// hand-off is not free (write-through stores, a drain, an atomic round trip, an L1
+// invalidate), which is why the chunk is 512 and not one tile.
 #define LONG_T 64             /* rows with more non-zeros than one tile leave the short path */
 #ifndef SPMM_RW
 #define SPMM_RW 4            /* consecutive short rows per wave */
 #endif
-#define LONG_CH 128
+#ifndef LONG_CH
+#define LONG_CH 512           /* measured on Gowalla: 64 -> 58 us, 128 -> 40, 256 -> 34, 512 -> 32.5, 768 -> 39, none -> 57 */
+#endif
 struct LongPlan {
     const int32_t *long_row;      // [n_long] row ids with nnz > LONG_T
     const int32_t *chunk_ptr;     // [n_long+1] prefix sum of chunks per long row
