@@ -527,7 +527,10 @@ __global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
     int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
     if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
     const int start = a.indptr[row], end = a.indptr[row + 1];
-    const int tiles = (end - start + 63) >> 6, per = (tiles + BPR_BW - 1) / BPR_BW;
+#ifndef ROWS_MIN_TILES
+#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
+#endif
+    const int tiles = (end - start + 63) >> 6, per = max((tiles + BPR_BW - 1) / BPR_BW, ROWS_MIN_TILES);
     const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
     if (q >= nparts) return;
     const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
