@@ -22,7 +22,7 @@ exactly like the reference's world.py.
 import importlib as _importlib
 
 __all__ = ["build", "_lib", "world", "parse", "register", "dataloader", "model", "utils",
-           "Procedure", "sampling", "parallel", "reorder"]
+           "Procedure", "sampling", "parallel", "reorder", "synthetic"]
 
 
 def __getattr__(name):

@@ -43,7 +43,9 @@ extern "C" void lgcn_set_error(const char *msg);   // lgcn_host.cpp
     } while (0)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __bf16 bf16_t;
 
 #ifndef LGCN_GATHER_U
@@ -52,61 +54,79 @@ typedef __bf16 bf16_t;
 #define FIXED_SCALE 1125899906842624.0   /* 2^50 */
 #define FIXED_INV   8.8817841970012523e-16 /* 2^-50 */
 
-__device__ __forceinline__ f32x4 load4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-__device__ __forceinline__ f32x4 load4(const bf16_t *p) {
-    bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
-    return __builtin_convertvector(v, f32x4);
+// C fp32 values per lane (C = 4: 16 B of fp32 / 8 B of bf16; C = 8: 32 B of fp32 / 16 B of bf16)
+template <int C> struct VecF;
+template <> struct VecF<4> { typedef f32x4 T; typedef bf16x4 B; };
+template <> struct VecF<8> { typedef f32x8 T; typedef bf16x8 B; };
+
+template <int C> __device__ __forceinline__ typename VecF<C>::T zerov() {
+    typename VecF<C>::T z;
+#pragma unroll
+    for (int i = 0; i < C; i++) z[i] = 0.f;
+    return z;
 }
-__device__ __forceinline__ void store4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
-__device__ __forceinline__ void store4(bf16_t *p, f32x4 v) {
-    *reinterpret_cast<bf16x4 *>(p) = __builtin_convertvector(v, bf16x4);
+template <int C> __device__ __forceinline__ typename VecF<C>::T loadv(const float *p) {
+    return *reinterpret_cast<const typename VecF<C>::T *>(p);
 }
-__device__ __forceinline__ f32x4 shfl_xor4(f32x4 v, int m) {
-    f32x4 r;
-    r.x = __shfl_xor(v.x, m); r.y = __shfl_xor(v.y, m); r.z = __shfl_xor(v.z, m); r.w = __shfl_xor(v.w, m);
-    return r;
+template <int C> __device__ __forceinline__ typename VecF<C>::T loadv(const bf16_t *p) {
+    return __builtin_convertvector(*reinterpret_cast<const typename VecF<C>::B *>(p), typename VecF<C>::T);
 }
+template <int C> __device__ __forceinline__ void storev(float *p, typename VecF<C>::T v) {
+    *reinterpret_cast<typename VecF<C>::T *>(p) = v;
+}
+template <int C> __device__ __forceinline__ void storev(bf16_t *p, typename VecF<C>::T v) {
+    *reinterpret_cast<typename VecF<C>::B *>(p) = __builtin_convertvector(v, typename VecF<C>::B);
+}
+__device__ __forceinline__ f32x4 load4(const float *p) { return loadv<4>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t *p) { return loadv<4>(p); }
+__device__ __forceinline__ void store4(float *p, f32x4 v) { storev<4>(p, v); }
+__device__ __forceinline__ void store4(bf16_t *p, f32x4 v) { storev<4>(p, v); }
 __device__ __forceinline__ bool bit_set(const uint32_t *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
 // fixed-point gradient row -> fp32 Gs row:  (float)(q * 2^-50) / (K+1)
-__device__ __forceinline__ f32x4 load4_fixed(const long long *p, float div) {
+template <int C> __device__ __forceinline__ typename VecF<C>::T loadv_fixed(const long long *p, float div) {
     typedef __attribute__((ext_vector_type(2))) long long i64x2_;
-    const i64x2_ a = *reinterpret_cast<const i64x2_ *>(p), b = *reinterpret_cast<const i64x2_ *>(p + 2);
-    f32x4 r;
-    r.x = (float)((double)a.x * FIXED_INV) / div; r.y = (float)((double)a.y * FIXED_INV) / div;
-    r.z = (float)((double)b.x * FIXED_INV) / div; r.w = (float)((double)b.y * FIXED_INV) / div;
+    typename VecF<C>::T r;
+#pragma unroll
+    for (int i = 0; i < C; i += 2) {
+        const i64x2_ a = *reinterpret_cast<const i64x2_ *>(p + i);
+        r[i] = (float)((double)a.x * FIXED_INV) / div; r[i + 1] = (float)((double)a.y * FIXED_INV) / div;
+    }
     return r;
 }
 
 struct GatherSrc {           // what a row gather reads
     const void *X;           // [N,D] of TI, or the fixed-point table when SPARSE
-    const uint32_t *bm;      // SPARSE: non-zero-row bitmap
+    const uint32_t *bm;      // SPARSE: non-zero-row bitmap (global, or the workgroup's LDS copy)
     float div;               // SPARSE: K+1
 };
 
-// Raw (unconverted) 4-column piece of a gathered row.  The conversion to fp32 is kept OUT
-// of the predicated load block: hipcc otherwise waits vmcnt(0) inside every block and the
-// U gathers serialise (measured: bf16 SpMM 2x slower than fp32).
+// Raw (unconverted) piece of a gathered row: 16 bytes per lane for fp32 AND bf16 tables (4 / 8
+// columns), so one wave-instruction always moves 1 KiB = 4 fp32 rows / 8 bf16 rows at d = 64 and the
+// bf16 table needs HALF the gather instructions of the fp32 one (with 8 B per lane the bf16 kernel
+// issued as many gathers as the fp32 one and was instruction-bound: +15 % for half the bytes).
+// The conversion to fp32 is kept OUT of the load block: hipcc otherwise waits vmcnt(0) inside every
+// block and the U gathers serialise (measured: bf16 SpMM 2x slower than fp32).
 typedef __attribute__((ext_vector_type(2))) long long i64x2;
 struct fixed4 { i64x2 a, b; };
 template <typename TI, bool SPARSE> struct Raw;
 template <> struct Raw<float, false> {
+    static constexpr int CPL = 4;
     typedef f32x4 T;
-    static __device__ __forceinline__ T zero() { return T{0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
         return *reinterpret_cast<const T *>((const float *)s.X + (int64_t)col * D + l * 4); }
     static __device__ __forceinline__ f32x4 cvt(const T &r, float) { return r; }
 };
 template <> struct Raw<bf16_t, false> {
-    typedef bf16x4 T;
-    static __device__ __forceinline__ T zero() { return __builtin_convertvector(f32x4{0.f, 0.f, 0.f, 0.f}, T); }
+    static constexpr int CPL = 8;
+    typedef bf16x8 T;
     static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
-        return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 4); }
-    static __device__ __forceinline__ f32x4 cvt(const T &r, float) { return __builtin_convertvector(r, f32x4); }
+        return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 8); }
+    static __device__ __forceinline__ f32x8 cvt(const T &r, float) { return __builtin_convertvector(r, f32x8); }
 };
 template <typename TI> struct Raw<TI, true> {
+    static constexpr int CPL = 4;
     typedef fixed4 T;
-    static __device__ __forceinline__ T zero() { return T{i64x2{0, 0}, i64x2{0, 0}}; }
     static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
         const long long *p = (const long long *)s.X + (int64_t)col * D + l * 4;
         return T{*reinterpret_cast<const i64x2 *>(p), *reinterpret_cast<const i64x2 *>(p + 2)}; }
@@ -116,20 +136,24 @@ template <typename TI> struct Raw<TI, true> {
         o.z = (float)((double)r.b.x * FIXED_INV) / div; o.w = (float)((double)r.b.y * FIXED_INV) / div;
         return o; }
 };
+// geometry of one kernel instance: columns per lane, lanes per row, neighbour rows per wave-instruction
+template <int D, typename TI, bool SPARSE> struct Geo {
+    static constexpr int CPL = Raw<TI, SPARSE>::CPL, LPR = D / CPL, NPW = 64 / LPR;
+    typedef typename VecF<CPL>::T Acc;
+};
 
 // ---------------------------------------------------------------------------------
 // One CSR row segment [start,end) of  A_hat * X  computed by one wavefront.
 //
 // The segment is walked in tiles of 64 non-zeros.  Per tile: every lane loads one
 // (col,val) pair -- one coalesced 256-byte read of each CSR stream -- and the tile is
-// staged in a wave-private LDS slot.  Then LPR = D/4 lanes cover one embedding row
-// with 4 columns each (16 B fp32 / 8 B bf16 per lane) and the wave's NPW = 64/LPR lane
-// groups take the staged neighbours interleaved, U deep, so every lane has up to U
-// independent row gathers in flight behind ONE index round trip.  SPARSE: only
-// neighbours whose row is flagged in the bitmap are staged (ballot + prefix-popcount
-// compaction), the rest cost no gather at all.
-// Partial sums are combined by xor-shuffles in a fixed order: deterministic, and
-// identical wherever this function is used.
+// staged in a wave-private LDS slot.  Then LPR lanes cover one embedding row with 16
+// bytes each and the wave's NPW = 64/LPR lane groups take the staged neighbours
+// interleaved, U deep, so every lane has up to U independent row gathers in flight
+// behind ONE index round trip.  SPARSE: only neighbours whose row is flagged in the
+// bitmap are staged (ballot + prefix-popcount compaction), the rest cost no gather.
+// Partial sums are combined across the lane groups in a fixed order: deterministic,
+// and identical wherever this function is used.
 // ---------------------------------------------------------------------------------
 // stage one tile of n <= 64 (col,val) pairs held one per lane; returns the staged count
 template <bool SPARSE>
@@ -149,16 +173,17 @@ __device__ __forceinline__ int tile_stage(int col, float val, int n, const Gathe
 
 // One batch of U gathers per lane: entries j0+g, j0+g+NPW, ... of the staged tile.
 template <int D, typename TI, bool SPARSE, int U>
-__device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
-    constexpr int LPR = D / 4, NPW = 64 / LPR;
+__device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt, const GatherSrc &src, int lane,
+                                             typename Geo<D, TI, SPARSE>::Acc &acc) {
+    typedef Geo<D, TI, SPARSE> G;
     typedef Raw<TI, SPARSE> R;
-    const int g = lane / LPR, l = lane % LPR;
+    const int g = lane / G::LPR, l = lane % G::LPR;
     int2 cv[U]; typename R::T x[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {                                        // all LDS reads first
         // past-the-end slots re-read the tile's last entry with weight 0: every gather is
         // unconditional (a predicated load makes hipcc wait for the previous one)
-        const int e = j0 + g + u * NPW;
+        const int e = j0 + g + u * G::NPW;
         cv[u] = stage[min(e, cnt - 1)];
         if (e >= cnt) cv[u].y = 0;
     }
@@ -169,14 +194,13 @@ __device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt,
     for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(x[u], src.div);
 }
 
-// Gather-accumulate the staged tile.  A 64-lane gather instruction costs the CU's L1 about
-// the same whether 1 or 4 of its row slots are useful (the kernel is bound by that issue rate,
-// not by bytes: bf16 rows are only ~10 % faster than fp32), so the batch depth follows the
-// (wave-uniform) number of staged neighbours instead of always issuing the deepest batch:
-// Gowalla's median row has 13 neighbours = 4 instructions, not 8.
+// Gather-accumulate the staged tile.  The batch depth follows the (wave-uniform) number of staged
+// neighbours instead of always issuing the deepest batch: a 64-lane gather instruction costs the
+// CU's address path the same whether 1 or all of its row slots are useful.
 template <int D, typename TI, bool SPARSE>
-__device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane, f32x4 &acc) {
-    constexpr int NPW = 64 / (D / 4), UMAX = SPARSE ? 2 : LGCN_GATHER_U;
+__device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane,
+                                            typename Geo<D, TI, SPARSE>::Acc &acc) {
+    constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 2 : LGCN_GATHER_U;
 #ifdef LGCN_EXP_NO_GATHER
     return;
 #endif
@@ -188,49 +212,80 @@ __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const Ga
     if (cnt - j > 0) gather_batch<D, TI, SPARSE, 1>(stage, j, cnt, src, lane, acc);
 }
 
-template <int D>
-__device__ __forceinline__ f32x4 reduce_groups(f32x4 acc) {
+// Sum over the lanes that hold the same columns (lane % LPR equal): every lane ends with the full
+// sum.  VALU only -- v_permlane32_swap / v_permlane16_swap (gfx950) exchange wave halves / 16-lane rows
+// without the LDS crossbar, DPP row rotations finish inside a row.  Fixed order: bitwise reproducible.
+__device__ __forceinline__ float sum_xor32(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const unsigned a = __float_as_uint(v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float sum_xor16(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const unsigned a = __float_as_uint(v);
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int ROT> __device__ __forceinline__ float sum_ror(float v) {      // + the lane ROT further in the 16-lane row
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROT, 0xf, 0xf, false));
+}
+template <int LPR, typename Acc>
+__device__ __forceinline__ Acc reduce_groups(Acc acc) {
+    constexpr int C = sizeof(Acc) / sizeof(float);
 #pragma unroll
-    for (int off = D / 4; off < 64; off <<= 1) acc += shfl_xor4(acc, off);
-    return acc;   // every lane group holds the full sum for its 4 columns
+    for (int i = 0; i < C; i++) {
+        float v = acc[i];
+        if (LPR <= 32) v = sum_xor32(v);
+        if (LPR <= 16) v = sum_xor16(v);
+        if (LPR <= 8) v = sum_ror<8>(v);
+        if (LPR <= 4) v = sum_ror<4>(v);
+        acc[i] = v;
+    }
+    return acc;   // every lane group holds the full sum for its columns
 }
 
 template <int D, typename TI, bool SPARSE>
-__device__ __forceinline__ f32x4 row_gather(const int32_t *__restrict__ indices,
-                                            const float *__restrict__ vals, int start, int end,
-                                            const GatherSrc &src, int lane, int2 *stage) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ typename Geo<D, TI, SPARSE>::Acc
+row_gather(const int32_t *__restrict__ indices, const float *__restrict__ vals, int start, int end,
+           const GatherSrc &src, int lane, int2 *stage) {
+    typedef Geo<D, TI, SPARSE> G;
+    typename G::Acc acc = zerov<G::CPL>();
+    // the next tile's (col,val) pair is in flight while this tile gathers
+    int col = 0; float val = 0.f;
+    if (start + lane < end) { col = indices[start + lane]; val = vals[start + lane]; }
     for (int base = start; base < end; base += 64) {
         const int n = min(64, end - base);
-        int col = 0; float val = 0.f;
-        if (lane < n) { col = indices[base + lane]; val = vals[base + lane]; }
         const int cnt = tile_stage<SPARSE>(col, val, n, src, lane, stage);
         __builtin_amdgcn_wave_barrier();
+        if (base + 64 + lane < end) { col = indices[base + 64 + lane]; val = vals[base + 64 + lane]; }
         tile_gather<D, TI, SPARSE>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
     }
-    return reduce_groups<D>(acc);
+    return reduce_groups<G::LPR>(acc);
 }
 
-// XCD-aware block->row-tile map: hardware deals workgroups round-robin over the 8
-// XCDs (speed-only observation), so give XCD x the x-th contiguous eighth of the
-// tiles: CSR / output streams of one L2 stay contiguous, and user rows (which
-// gather item rows) and item rows (which gather user rows) land on disjoint XCDs.
-__device__ __forceinline__ int64_t tile_of_block(int64_t bid, int64_t ntiles, int remap) {
-    if (!remap) return bid;
-    const int64_t per = (ntiles + 7) / 8;
-    return (bid & 7) * per + (bid >> 3);   // may be >= ntiles: caller checks
-}
-
-// Rows with more than LONG_T (= one 64-entry tile) non-zeros leave the short-row path and run as
-// independent waves at the FRONT of the grid (they start first, so their serial tile walk
-// overlaps everything else).  Rows up to LONG_CH non-zeros are finished by one wave.  Longer
-// rows are cut into chunks of LONG_CH (a single wave walking Gowalla's 1415-nnz row = 23
-// serial tiles was the critical path = the entire 57 us of the un-split launch): each chunk
-// writes a partial row and takes a ticket, and the LAST arriver sums the partials in chunk
-// order (fixed order: bitwise reproducible whoever is last) and runs the epilogue.  The
-// hand-off is not free (write-through stores, a drain, an atomic round trip, an L1
-// invalidate), which is why the chunk is 512 and not one tile.
+// ---------------------------------------------------------------------------------
+// Work plan of one graph (built on the host at lgcn_graph_create).
+//
+// The processing order of the rows is cut into 8 slices, one per XCD (hardware deals
+// workgroups round-robin over the 8 XCDs -- speed-only observation -- so block b works on
+// slice b & 7).  A slice's rows mostly gather rows of the same part of the graph
+// (reorder.py), so the part of the table an XCD touches is a fraction of the whole and
+// lives in that XCD's 4 MiB L2.  Inside a slice:
+//   * rows with more than LONG_T (= one 64-entry tile) non-zeros run as independent waves at
+//     the FRONT of the slice (they start first: their serial tile walk overlaps everything
+//     else).  Rows up to LONG_CH non-zeros are finished by one wave; longer rows are cut into
+//     chunks of LONG_CH (a single wave walking Gowalla's 1415-nnz row = 23 serial tiles was
+//     the critical path = the entire 57 us of an un-split launch): each chunk writes a partial
+//     row and takes a ticket, and the LAST arriver sums the partials in chunk order (fixed
+//     order: bitwise reproducible whoever is last) and runs the epilogue.  The hand-off is not
+//     free (write-through stores, a drain, an atomic round trip, an L1 invalidate), which is
+//     why the chunk is 512 and not one tile.  Long rows stay in the slice of their part of the
+//     graph: they are 29 % of Gowalla's non-zeros, and dealt round-robin over the XCDs (round 1)
+//     they alone produced half of the L2 misses.
+//   * the other rows go SPMM_RW per wave, 4 waves per workgroup, in order.
+// ---------------------------------------------------------------------------------
 #define LONG_T 64             /* rows with more non-zeros than one tile leave the short path */
 #ifndef SPMM_RW
 #define SPMM_RW 4            /* consecutive short rows per wave */
@@ -238,27 +293,33 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t bid, int64_t ntiles, in
 #ifndef LONG_CH
 #define LONG_CH 512           /* measured on Gowalla: 64 -> 58 us, 128 -> 40, 256 -> 34, 512 -> 32.5, 768 -> 39, none -> 57 */
 #endif
+#define XCDS 8
 struct LongPlan {
+    const int4 *chunks;           // [n_chunk_slots] (index o into long_row | -1 = padding, first nnz, end nnz, ordinal in row)
     const int32_t *long_row;      // [n_long] row ids with nnz > LONG_T
-    const int32_t *chunk_ptr;     // [n_long+1] prefix sum of chunks per long row
-    const int32_t *chunk_owner;   // [n_chunks] index into long_row
-    float *partials;              // [n_chunks, D]
+    const int32_t *long_nch;      // [n_long] chunks of that row
+    float *partials;              // [n_chunk_slots, D]  (slot = position in `chunks`)
     int32_t *counters;            // [n_long] arrival tickets (zero between launches)
-    int32_t n_long, n_chunks;
+    int32_t n_long, n_chunk_slots;
+};
+struct SlicePlan {                // per XCD slice x: chunk blocks [cblk[x], cblk[x+1]) then row tiles [tile[x], tile[x+1])
+    int32_t cblk[XCDS + 1];
+    int32_t tile[XCDS + 1];
 };
 
 struct SpmmArgs {
-    const int32_t *indptr; const int32_t *indices; const float *vals;
-    const int4 *rowinfo;          // per position of the processing order: (row, first nnz, nnz count, 0)
-    LongPlan lp;
+    const int32_t *indices; const float *vals;
+    const int4 *rowinfo;          // short rows of the slices, padded per slice: (row | -1, first nnz, nnz count, 0)
+    LongPlan lp; SlicePlan sp;
     const void *X; void *Y;
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
+    int32_t bm_words;             // > 0: the kernel copies the bitmap into LDS (dynamic shared memory) first
     float *P; float *M; float *V;
+    bf16_t *Pb;                   // optional bf16 shadow of P written by the Adam epilogue
     // last kernel of a step (K >= 2): its epilogue zeroes the G64 rows / bitmap bits it consumes and one
     // wave reduces the per-triplet loss terms, so no separate clean-up launch is needed
     int clear;
     const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
-    int64_t n_rows;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
 };
@@ -267,31 +328,34 @@ enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
 
 //   M_ADDG  : add Gs[row] where flagged (Horner term)
 //   M_ADAM  : apply torch.optim.Adam to P/M/V with grad = result, else store to Y
-template <int D, typename TO, int MODE>
-__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, f32x4 acc) {
-    const int64_t off = row * D + l * 4;
+template <int D, typename TO, int MODE, int C>
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc) {
+    typedef typename VecF<C>::T V;
+    const int64_t off = row * D + l * C;
     if ((MODE & M_ADDG) && bit_set(a.bitmap, (int)row)) {
-        f32x4 g = load4_fixed(a.G64 + off, a.div);
+        V g = loadv_fixed<C>(a.G64 + off, a.div);
         acc = g + acc;
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
             //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
             //  k_bpr_loss of the next step zeroes the stale one with plain stores)
             i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
-            q[0] = i64x2{0, 0}; q[1] = i64x2{0, 0};
+#pragma unroll
+            for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
         }
     }
     if (MODE & M_ADAM) {
-        f32x4 p = load4(a.P + off), m = load4(a.M + off), v = load4(a.V + off);
+        V p = loadv<C>(a.P + off), m = loadv<C>(a.M + off), v = loadv<C>(a.V + off);
         m = m + a.w1 * (acc - m);                       // exp_avg.lerp_(grad, 1-beta1)
         v = v * a.beta2 + (a.omb2 * acc) * acc;         // mul_(beta2).addcmul_(g,g,1-beta2)
-        f32x4 denom;
-        denom.x = sqrtf(v.x) / a.bc2_sqrt + a.eps; denom.y = sqrtf(v.y) / a.bc2_sqrt + a.eps;
-        denom.z = sqrtf(v.z) / a.bc2_sqrt + a.eps; denom.w = sqrtf(v.w) / a.bc2_sqrt + a.eps;
+        V denom;
+#pragma unroll
+        for (int i = 0; i < C; i++) denom[i] = sqrtf(v[i]) / a.bc2_sqrt + a.eps;
         p = p - a.step_size * (m / denom);              // addcdiv_(exp_avg, denom, -step_size)
-        store4(a.P + off, p); store4(a.M + off, m); store4(a.V + off, v);
+        storev<C>(a.P + off, p); storev<C>(a.M + off, m); storev<C>(a.V + off, v);
+        if (a.Pb) storev<C>(a.Pb + off, p);
     } else {
-        store4((TO *)a.Y + off, acc);
+        storev<C>((TO *)a.Y + off, acc);
     }
 }
 
@@ -319,49 +383,73 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
     }
 }
 
-// Y = [Gs +] A_hat X.  256-thread workgroups = 4 waves.  Blocks [0, chunk_blocks) run one
-// long-row chunk per wave, the remaining blocks one short row per wave.
+// Y = [Gs +] A_hat X.  256-thread workgroups = 4 waves.  Block b works on slice b & 7 (b >> 3 -th
+// block of it): first the slice's long-row chunks, one per wave, then its short rows.
 //   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
 #ifndef SPMM_MIN_WAVES
 #define SPMM_MIN_WAVES 8      /* waves per SIMD the register allocation must allow (<= 64 VGPRs) */
 #endif
+#ifndef SPMM_MIN_WAVES_BF16
+#define SPMM_MIN_WAVES_BF16 6 /* 8 columns per lane: 8-register accumulators and 4 x 16-byte raw pieces need <= 80 VGPRs */
+#endif
 template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
-    constexpr int LPR = D / 4;
+__global__ void __launch_bounds__(256, (sizeof(TI) == 2 && !(MODE & M_SPARSE)) ? SPMM_MIN_WAVES_BF16 : SPMM_MIN_WAVES)
+k_spmm(SpmmArgs a) {
+    constexpr bool SP = (MODE & M_SPARSE) != 0;
+    typedef Geo<D, TI, SP> G;
+    typedef typename G::Acc Acc;
+    constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
     __shared__ int2 stage_lds[4][64];
+    extern __shared__ uint32_t bm_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    GatherSrc src;
+    src.X = SP ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
+    if (SP && a.bm_words > 0) {
+        // the bitmap test of every neighbour is a dependent round trip when it goes to L2; the whole
+        // bitmap of a <= 131 k-row graph is <= 16 KiB: copy it into LDS once per workgroup
+        for (int i = threadIdx.x; i < a.bm_words; i += 256) bm_lds[i] = a.bitmap[i];
+        __syncthreads();
+        src.bm = bm_lds;
+    }
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
     //  sat on the tail and cost +25 us)
-    if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear && blockIdx.x == 0 && wid == 3)
+    if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == 3)
         reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane);
-    GatherSrc src;
-    src.X = (MODE & M_SPARSE) ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
-    const int chunk_blocks = (a.lp.n_chunks + 3) >> 2;
-    if ((int)blockIdx.x < chunk_blocks) {
+    int x, j;
+    if (a.remap) { x = blockIdx.x & (XCDS - 1); j = blockIdx.x >> 3; }
+    else {        // slices as contiguous block ranges (placement-independent either way: speed only)
+        x = 0; j = blockIdx.x;
+        while (x < XCDS - 1) {
+            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.tile[x + 1] - a.sp.tile[x]);
+            if (j < nb) break;
+            j -= nb; x++;
+        }
+    }
+    const int ncb = a.sp.cblk[x + 1] - a.sp.cblk[x];
+    if (j < ncb) {
         // ---- one chunk of a long row ----
-        const int c = blockIdx.x * 4 + wid;
-        if (c >= a.lp.n_chunks) return;
-        const int o = a.lp.chunk_owner[c];
+        const int c = (a.sp.cblk[x] + j) * 4 + wid;
+        const int4 ch = a.lp.chunks[c];
+        const int o = ch.x;
+        if (o < 0) return;
         const int64_t row = a.lp.long_row[o];
-        const int first = a.lp.chunk_ptr[o], nch = a.lp.chunk_ptr[o + 1] - first;
-        const int rs = a.indptr[row], re = a.indptr[row + 1];
-        const int s0 = rs + (c - first) * LONG_CH, s1 = min(re, s0 + LONG_CH);
-        f32x4 acc = row_gather<D, TI, (MODE & M_SPARSE) != 0>(a.indices, a.vals, s0, s1, src, lane, stage_lds[wid]);
-        if (nch == 1) {                                   // 65..128 non-zeros: one wave, no hand-off
-            if (lane < LPR) spmm_epilogue<D, TO, MODE>(a, row, lane, acc);
+        const int nch = a.lp.long_nch[o];
+        Acc acc = row_gather<D, TI, SP>(a.indices, a.vals, ch.y, ch.z, src, lane, stage_lds[wid]);
+        if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
+            if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc);
             return;
         }
-        // Publish the partial WRITE-THROUGH (sc1: two 8-byte agent-scope stores per lane, no release
-        // fence -- a release would write back this XCD's whole dirty L2, measured 2x on the launch),
-        // drain, take a ticket; the last arriver invalidates its L1 once and reads the partials
-        // (cdna guide G16, R1 form with a counter).
+        // Publish the partial WRITE-THROUGH (sc1: 8-byte agent-scope stores, no release fence -- a
+        // release would write back this XCD's whole dirty L2, measured 2x on the launch), drain, take
+        // a ticket; the last arriver invalidates its L1 once and reads the partials with sc1 loads
+        // (cdna guide G16: R1 form with a counter, both the acquire AND the sc1-load variant).
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
         if (lane < LPR) {
-            typedef __attribute__((address_space(1))) unsigned long long gu64;
-            union { f32x4 v; unsigned long long q[2]; } pk; pk.v = acc;
-            gu64 *dst = (gu64 *)(a.lp.partials + (int64_t)c * D + lane * 4);
-            __hip_atomic_store(dst, pk.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, pk.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            union { Acc v; unsigned long long q[C / 2]; } pk; pk.v = acc;
+            gu64 *dst = (gu64 *)(a.lp.partials + (int64_t)c * D + lane * C);
+#pragma unroll
+            for (int i = 0; i < C / 2; i++) __hip_atomic_store(dst + i, pk.q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int ticket = 0;
@@ -372,72 +460,63 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(a.lp.counters + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
         if (lane >= LPR) return;
-        f32x4 tot = load4(a.lp.partials + (int64_t)first * D + lane * 4);
-        for (int j = 1; j < nch; j++) tot += load4(a.lp.partials + (int64_t)(first + j) * D + lane * 4);
-        spmm_epilogue<D, TO, MODE>(a, row, lane, tot);
+        const int first = c - ch.w;
+        Acc tot = zerov<C>();
+        for (int k = 0; k < nch; k++) {
+            union { Acc v; unsigned long long q[C / 2]; } pk;
+            gu64 *s = (gu64 *)(a.lp.partials + (int64_t)(first + k) * D + lane * C);
+#pragma unroll
+            for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 0) tot = pk.v; else tot += pk.v;
+        }
+        spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot);
         return;
     }
-    // ---- SPMM_RW short rows per wave, consecutive in the PROCESSING ORDER (a locality
-    //      ordering of the graph: rows that share neighbours run close together in time and on
-    //      the same XCD, so their gathers hit that XCD's L2; memory layout is untouched).  Rows
-    //      are walked one after the other; the first index tile of row r+1 is in flight while
-    //      row r gathers. ----
-    const int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
-    const int64_t tile = tile_of_block((int64_t)blockIdx.x - chunk_blocks, ntiles, a.remap);
-    if (tile >= ntiles) return;
-    const int64_t pos0 = (tile * 4 + wid) * SPMM_RW;
-    if (pos0 >= a.n_rows) return;
+    // ---- SPMM_RW short rows per wave, consecutive in the PROCESSING ORDER.  Rows are walked one
+    //      after the other; the index tile of row r+1 is in flight while row r gathers. ----
+    const int t = j - ncb;
+    if (t >= a.sp.tile[x + 1] - a.sp.tile[x]) return;
+    const int64_t pos0 = ((int64_t)(a.sp.tile[x] + t) * 4 + wid) * SPMM_RW;
     // lane r < SPMM_RW fetches (row id, first nnz, count) of its row with ONE 16-byte load from the
     // plan (order -> indptr would be two dependent round trips); then wave-uniform registers
-    int my_row = -1, my_s = 0, my_e = 0;
-    if (lane < SPMM_RW && pos0 + lane < a.n_rows) {
+    int my_row = -1, my_s = 0, my_n = 0;
+    if (lane < SPMM_RW) {
         const int4 ri = a.rowinfo[pos0 + lane];
-        my_row = ri.x; my_s = ri.y; my_e = ri.y + ri.z;
+        my_row = ri.x; my_s = ri.y; my_n = ri.z;
     }
-    int rows[SPMM_RW], ip_s[SPMM_RW], ip_e[SPMM_RW];
+    int rows[SPMM_RW], ip_s[SPMM_RW], ip_n[SPMM_RW];
 #pragma unroll
     for (int r = 0; r < SPMM_RW; r++) {
         rows[r] = __builtin_amdgcn_readlane(my_row, r);
-        ip_s[r] = __builtin_amdgcn_readlane(my_s, r); ip_e[r] = __builtin_amdgcn_readlane(my_e, r);
+        ip_s[r] = __builtin_amdgcn_readlane(my_s, r); ip_n[r] = __builtin_amdgcn_readlane(my_n, r);
     }
-    const bool split = a.lp.n_chunks > 0;
+    if (rows[0] < 0) return;                 // padding is at the end of a slice: nothing in this wave
     int col_n = 0; float val_n = 0.f;
-    {   // first tile of row 0
-        const int deg = ip_e[0] - ip_s[0];
-        if (!(split && deg > LONG_T) && lane < deg) { col_n = a.indices[ip_s[0] + lane]; val_n = a.vals[ip_s[0] + lane]; }
-    }
-    // Results are flushed every NPW rows: group g finishes row q+g, so an epilogue pass keeps all 64
-    // lanes busy (epilogue after every single row made the next row's staging wait for the store).
-    constexpr int NPW = 64 / LPR;
+    if (lane < ip_n[0]) { col_n = a.indices[ip_s[0] + lane]; val_n = a.vals[ip_s[0] + lane]; }
+    // Results are flushed every NPW rows: lane group g keeps the sum of row q+g, so an epilogue pass
+    // keeps all 64 lanes busy (an epilogue after every single row made the next row's staging wait
+    // for the store).
     const int g = lane / LPR, l = lane % LPR;
-    f32x4 out[NPW];
-    unsigned live_mask = 0;
+    Acc mine = zerov<C>();
+    int mrow = -1;
 #pragma unroll
     for (int r = 0; r < SPMM_RW; r++) {
-        const int start = ip_s[r], end = ip_e[r];
-        const bool live = (rows[r] >= 0) && !(split && end - start > LONG_T);   // long rows: done by chunks
+        const bool live = rows[r] >= 0;
         int cnt = 0;
-        if (live) cnt = tile_stage<(MODE & M_SPARSE) != 0>(col_n, val_n, min(64, end - start), src, lane, stage_lds[wid]);
+        if (live) cnt = tile_stage<SP>(col_n, val_n, ip_n[r], src, lane, stage_lds[wid]);
         __builtin_amdgcn_wave_barrier();
         if (r + 1 < SPMM_RW) {          // first tile of the next row: in flight during this row's gathers
-            const int ns = ip_s[r + 1 < SPMM_RW ? r + 1 : r], ndeg = ip_e[r + 1 < SPMM_RW ? r + 1 : r] - ns;
-            if (!(split && ndeg > LONG_T) && lane < ndeg) { col_n = a.indices[ns + lane]; val_n = a.vals[ns + lane]; }
+            const int ns = ip_s[r + 1 < SPMM_RW ? r + 1 : r], nn = ip_n[r + 1 < SPMM_RW ? r + 1 : r];
+            if (lane < nn) { col_n = a.indices[ns + lane]; val_n = a.vals[ns + lane]; }
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-            tile_gather<D, TI, (MODE & M_SPARSE) != 0>(stage_lds[wid], cnt, src, lane, acc);
-            live_mask |= 1u << r;
-        }
+        Acc acc = zerov<C>();
+        if (live) tile_gather<D, TI, SP>(stage_lds[wid], cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
-        out[r % NPW] = reduce_groups<D>(acc);
+        acc = reduce_groups<LPR>(acc);
+        if (g == r % NPW) { mine = acc; mrow = rows[r]; }
         if (r % NPW == NPW - 1 || r == SPMM_RW - 1) {
-            const int q = r - (r % NPW);
-            f32x4 mine = out[0];
-            int mrow = rows[q];
-#pragma unroll
-            for (int t = 1; t < NPW; t++) if (q + t <= r && g == t) { mine = out[t]; mrow = rows[q + t]; }
-            const int rr = q + g;
-            if (rr <= r && ((live_mask >> rr) & 1u)) spmm_epilogue<D, TO, MODE>(a, mrow, l, mine);
+            if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, mine);
+            mrow = -1;
         }
     }
 }
@@ -516,45 +595,52 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
 #ifndef BPR_BW
 #define BPR_BW 4
 #endif
+#ifndef ROWS_MIN_TILES
+#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
+#endif
+// TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
+template <int D, typename TG, typename TI>
+__device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int64_t row, int s0, int s1, int q, int nparts,
+                                          int lane, int2 *stage, float (*part)[D]) {
+    typedef Geo<D, TG, false> G;
+    constexpr int C = G::CPL, LPR = G::LPR;
+    GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
+    typename G::Acc xk = row_gather<D, TG, false>(a.indices, a.vals, s0, s1, src, lane, stage);
+    if (nparts > 1) {
+        if (lane < LPR) storev<C>(&part[q][lane * C], xk);
+        __syncthreads();
+        if (q != 0) return;
+        if (lane < LPR) {
+            xk = loadv<C>(&part[0][lane * C]);
+            for (int w = 1; w < nparts; w++) xk += loadv<C>(&part[w][lane * C]);
+        }
+    }
+    if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
+        const int64_t off = row * D + lane * C;
+        typename G::Acc s = loadv<C>(a.X0 + off);
+        for (int k = 1; k < a.K; k++) s += loadv<C>((const TI *)a.Xl[k] + off);
+        s += xk;
+        const float div = (float)(a.K + 1);
+        storev<C>(a.ebuf + (int64_t)blockIdx.x * D + lane * C, s / div);
+    }
+}
+
 template <int D, typename TI>
 __global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
-    constexpr int LPR = D / 4;
     __shared__ int2 stage_lds[BPR_BW][64];
-    __shared__ __attribute__((aligned(16))) float part_lds[BPR_BW][D];
+    __shared__ __attribute__((aligned(32))) float part_lds[BPR_BW][D];
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
     int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
     if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
     const int start = a.indptr[row], end = a.indptr[row + 1];
-#ifndef ROWS_MIN_TILES
-#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
-#endif
     const int tiles = (end - start + 63) >> 6, per = max((tiles + BPR_BW - 1) / BPR_BW, ROWS_MIN_TILES);
     const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
     if (q >= nparts) return;
     const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
-    GatherSrc src; src.bm = nullptr; src.div = 1.f;
-    f32x4 xk;
-    if (a.K == 1) { src.X = a.X0; xk = row_gather<D, float, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[q]); }
-    else { src.X = a.Xl[a.K - 1]; xk = row_gather<D, TI, false>(a.indices, a.vals, s0, s1, src, lane, stage_lds[q]); }
-    if (nparts > 1) {
-        if (lane < LPR) store4(&part_lds[q][lane * 4], xk);
-        __syncthreads();
-        if (q != 0) return;
-        if (lane < LPR) {
-            xk = load4(&part_lds[0][lane * 4]);
-            for (int w = 1; w < nparts; w++) xk += load4(&part_lds[w][lane * 4]);
-        }
-    }
-    if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
-        const int64_t off = row * D + lane * 4;
-        f32x4 s = load4(a.X0 + off);
-        for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + off);
-        s += xk;
-        const float div = (float)(a.K + 1);
-        store4(a.ebuf + (int64_t)blockIdx.x * D + lane * 4, s / div);
-    }
+    if (a.K == 1) rows_body<D, float, TI>(a, a.X0, row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
+    else rows_body<D, TI, TI>(a, a.Xl[a.K - 1], row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
 }
 
 // Lane = column (mod 64): every load, store and atomic wave-instruction of a triplet covers
@@ -702,32 +788,40 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
+#define BM_LDS_MAX_WORDS 4096     /* 16 KiB: with the 2 KiB stage, 8 workgroups still fit a CU's 160 KiB */
 template <int D, typename TI, typename TO, int MODE>
-static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
-    int64_t ntiles = (a.n_rows + 4 * SPMM_RW - 1) / (4 * SPMM_RW);
-    if (a.remap) ntiles = ((ntiles + 7) / 8) * 8;
-    const unsigned grid = (unsigned)ntiles + (unsigned)((a.lp.n_chunks + 3) / 4);
-    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), 0, st, a);
+static void launch_spmm_t(SpmmArgs a, int64_t bm_words, hipStream_t st) {
+    unsigned grid = 0, widest = 0;
+    for (int x = 0; x < XCDS; x++) {
+        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.tile[x + 1] - a.sp.tile[x]));
+        grid += nb; widest = nb > widest ? nb : widest;
+    }
+    if (a.remap) grid = widest * XCDS;
+    if (grid == 0) return;
+    size_t dyn = 0;
+    a.bm_words = 0;
+    if ((MODE & M_SPARSE) && bm_words > 0 && bm_words <= BM_LDS_MAX_WORDS) { a.bm_words = (int32_t)bm_words; dyn = 4 * (size_t)bm_words; }
+    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), dyn, st, a);
 }
 
 template <int D, int MODE>
-static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, hipStream_t st) {
+static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, int64_t bm_words, hipStream_t st) {
     if (MODE & M_SPARSE) x_dtype = LGCN_F32;           // source is the fixed-point table; TI unused
     if (MODE & M_ADAM) y_dtype = LGCN_F32;
-    if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, st);
-    else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, st);
-    else if (x_dtype == LGCN_BF16 && y_dtype == LGCN_F32) launch_spmm_t<D, bf16_t, float, MODE>(a, st);
-    else launch_spmm_t<D, bf16_t, bf16_t, MODE>(a, st);
+    if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, bm_words, st);
+    else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, bm_words, st);
+    else if (x_dtype == LGCN_BF16 && y_dtype == LGCN_F32) launch_spmm_t<D, bf16_t, float, MODE>(a, bm_words, st);
+    else launch_spmm_t<D, bf16_t, bf16_t, MODE>(a, bm_words, st);
     return 0;
 }
 
 template <int MODE>
-static int launch_spmm(const SpmmArgs &a, int d, int x_dtype, int y_dtype, hipStream_t st) {
+static int launch_spmm(const SpmmArgs &a, int d, int x_dtype, int y_dtype, hipStream_t st, int64_t bm_words = 0) {
     switch (d) {
-    case 32: return launch_spmm_d<32, MODE>(a, x_dtype, y_dtype, st);
-    case 64: return launch_spmm_d<64, MODE>(a, x_dtype, y_dtype, st);
-    case 128: return launch_spmm_d<128, MODE>(a, x_dtype, y_dtype, st);
-    case 256: return launch_spmm_d<256, MODE>(a, x_dtype, y_dtype, st);
+    case 32: return launch_spmm_d<32, MODE>(a, x_dtype, y_dtype, bm_words, st);
+    case 64: return launch_spmm_d<64, MODE>(a, x_dtype, y_dtype, bm_words, st);
+    case 128: return launch_spmm_d<128, MODE>(a, x_dtype, y_dtype, bm_words, st);
+    case 256: return launch_spmm_d<256, MODE>(a, x_dtype, y_dtype, bm_words, st);
     }
     lgcn_set_error("embedding dim must be 32, 64, 128 or 256");
     return 3;
@@ -760,19 +854,56 @@ struct lgcn_graph {
     const int32_t *indptr; const int32_t *indices; const float *vals; const int4 *rowinfo;
     int64_t n_rows, nnz;
     int32_t d_max;
-    LongPlan lp;
+    LongPlan lp; SlicePlan sp;
     void *owned;          // one device allocation holding plan arrays, partials and counters
+    // The long-row scratch (partials, tickets) is shared by every launch on this graph: launches
+    // are ordered.  A launch on another stream than the previous one first waits for it.
+    mutable hipStream_t last_stream; mutable bool used; mutable hipEvent_t order_ev;
 };
+
+// a launch on `st` is about to use the graph's scratch: order it behind the previous user
+static int graph_acquire(const lgcn_graph *g, hipStream_t st) {
+    if (g->used && g->last_stream != st) {
+        HIP_OK(hipEventRecord(g->order_ev, g->last_stream));
+        HIP_OK(hipStreamWaitEvent(st, g->order_ev, 0));
+    }
+    g->used = true; g->last_stream = st;
+    return 0;
+}
+
+// column indices must address rows of X: flag any index outside [0, n_rows)
+__global__ void __launch_bounds__(256) k_index_range(const int32_t *indices, int64_t nnz, int32_t n_rows, int32_t *bad) {
+    bool b = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        const int32_t c = indices[i];
+        b |= (c < 0 || c >= n_rows);
+    }
+    if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
 
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                                  int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                                 lgcn_graph **out) {
+                                 const int64_t *xcd_start, lgcn_graph **out) {
     if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
         n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
     if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
     std::vector<int32_t> ip((size_t)n_rows + 1);
     HIP_OK(hipMemcpy(ip.data(), indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost));
     if (ip[0] != 0 || (int64_t)ip[(size_t)n_rows] != nnz) { lgcn_set_error("lgcn_graph_create: indptr does not match nnz"); return 3; }
+    if (nnz > 0) {               // a bad column index would become an out-of-bounds row gather
+        int32_t *bad = nullptr, hbad = 0;
+        HIP_OK(hipMalloc((void **)&bad, sizeof(int32_t)));
+        hipError_t e0 = hipMemset(bad, 0, sizeof(int32_t));
+        if (e0 == hipSuccess) {
+            const int64_t blocks = (nnz + 255) / 256;
+            hipLaunchKernelGGL(k_index_range, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, 0,
+                               indices, nnz, (int32_t)n_rows, bad);
+            e0 = hipMemcpy(&hbad, bad, sizeof(int32_t), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(bad);
+        if (e0 != hipSuccess) { lgcn_set_error("lgcn_graph_create: index check failed to run"); return 10; }
+        if (hbad) { lgcn_set_error("lgcn_graph_create: column index out of range [0, n_rows)"); return 3; }
+    }
     std::vector<int32_t> ord;
     if (row_order) {             // must be a permutation of 0..n_rows-1
         ord.resize((size_t)n_rows);
@@ -784,51 +915,85 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             seen[(size_t)r] = 1;
         }
     }
-    std::vector<int32_t> long_row, chunk_ptr(1, 0), owner;
-    for (int64_t r = 0; r < n_rows; r++) {
-        const int64_t deg = (int64_t)ip[(size_t)r + 1] - ip[(size_t)r];
-        if (deg < 0) { lgcn_set_error("lgcn_graph_create: indptr not monotone"); return 3; }
-        if (deg > LONG_T) {
-            const int nch = (int)((deg + LONG_CH - 1) / LONG_CH);
-            for (int k = 0; k < nch; k++) owner.push_back((int32_t)long_row.size());
-            long_row.push_back((int32_t)r);
-            chunk_ptr.push_back(chunk_ptr.back() + nch);
+    for (int64_t r = 0; r < n_rows; r++)
+        if (ip[(size_t)r + 1] < ip[(size_t)r]) { lgcn_set_error("lgcn_graph_create: indptr not monotone"); return 3; }
+    // ---- slices of the processing order, one per XCD
+    int64_t xs[XCDS + 1];
+    if (xcd_start) {
+        for (int x = 0; x <= XCDS; x++) xs[x] = xcd_start[x];
+        bool ok = xs[0] == 0 && xs[XCDS] == n_rows;
+        for (int x = 0; x < XCDS; x++) ok = ok && xs[x] <= xs[x + 1];
+        if (!ok) { lgcn_set_error("lgcn_graph_create: xcd_start must be 9 non-decreasing positions from 0 to n_rows"); return 3; }
+    } else {                     // balance the work: non-zeros plus a per-row constant
+        const double total = (double)nnz + 4.0 * (double)n_rows;
+        double acc = 0.0; int x = 1;
+        xs[0] = 0;
+        for (int64_t p = 0; p < n_rows && x < XCDS; p++) {
+            const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
+            acc += (double)(ip[(size_t)r + 1] - ip[(size_t)r]) + 4.0;
+            while (x < XCDS && acc >= total * x / XCDS) xs[x++] = p + 1;
         }
+        while (x <= XCDS) xs[x++] = n_rows;
+        xs[XCDS] = n_rows;
     }
-    std::vector<int32_t> rowinfo((size_t)n_rows * 4);
-    for (int64_t p = 0; p < n_rows; p++) {
-        const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
-        rowinfo[(size_t)p * 4 + 0] = r; rowinfo[(size_t)p * 4 + 1] = ip[(size_t)r];
-        rowinfo[(size_t)p * 4 + 2] = ip[(size_t)r + 1] - ip[(size_t)r]; rowinfo[(size_t)p * 4 + 3] = 0;
+    // ---- per slice: chunks of its long rows (padded to whole workgroups), then its short rows
+    std::vector<int32_t> long_row, long_nch, chunks, rowinfo;
+    SlicePlan sp{};
+    rowinfo.reserve((size_t)n_rows * 4 + 64 * XCDS);
+    for (int x = 0; x < XCDS; x++) {
+        sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.tile[x] = (int32_t)(rowinfo.size() / (4 * 4 * SPMM_RW));
+        for (int64_t p = xs[x]; p < xs[x + 1]; p++) {
+            const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
+            const int32_t s0 = ip[(size_t)r], deg = ip[(size_t)r + 1] - s0;
+            if (deg > LONG_T) {
+                const int nch = (deg + LONG_CH - 1) / LONG_CH;
+                for (int k = 0; k < nch; k++) {
+                    const int32_t c0 = s0 + k * LONG_CH, c1 = c0 + LONG_CH < s0 + deg ? c0 + LONG_CH : s0 + deg;
+                    const int32_t e[4] = {(int32_t)long_row.size(), c0, c1, k};
+                    chunks.insert(chunks.end(), e, e + 4);
+                }
+                long_row.push_back(r); long_nch.push_back(nch);
+            } else {
+                const int32_t e[4] = {r, s0, deg, 0};
+                rowinfo.insert(rowinfo.end(), e, e + 4);
+            }
+        }
+        const int32_t pad[4] = {-1, 0, 0, 0};
+        while ((chunks.size() / 4) % 4) chunks.insert(chunks.end(), pad, pad + 4);
+        while ((rowinfo.size() / 4) % (4 * SPMM_RW)) rowinfo.insert(rowinfo.end(), pad, pad + 4);
     }
+    sp.cblk[XCDS] = (int32_t)(chunks.size() / 16); sp.tile[XCDS] = (int32_t)(rowinfo.size() / (4 * 4 * SPMM_RW));
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
     g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr;
     g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
-    g->owned = nullptr; g->lp = LongPlan{};
-    const size_t n_long = long_row.size(), n_chunks = owner.size();
+    g->owned = nullptr; g->lp = LongPlan{}; g->sp = sp;
+    g->used = false; g->last_stream = nullptr; g->order_ev = nullptr;
+    if (hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipEventCreate failed"); return 10; }
+    const size_t n_long = long_row.size(), n_slots = chunks.size() / 4, n_info = rowinfo.size() / 4;
     {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const size_t o_info = 0, o_row = up(o_info + 16 * (size_t)n_rows), o_ptr = up(o_row + 4 * n_long),
-                     o_own = up(o_ptr + 4 * (n_long + 1)), o_cnt = up(o_own + 4 * n_chunks),
-                     o_par = up(o_cnt + 4 * n_long), total = o_par + n_chunks * (size_t)d_max * 4 + 256;
+        const size_t o_info = 0, o_chk = up(o_info + 16 * n_info), o_row = up(o_chk + 16 * n_slots),
+                     o_nch = up(o_row + 4 * n_long), o_cnt = up(o_nch + 4 * n_long),
+                     o_par = up(o_cnt + 4 * n_long), total = o_par + n_slots * (size_t)d_max * 4 + 256;
         char *base = nullptr;
-        if (hipMalloc((void **)&base, total) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
+        if (hipMalloc((void **)&base, total) != hipSuccess) { (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
         g->owned = base;
         hipError_t e1 = hipMemset(base, 0, total);
-        if (e1 == hipSuccess) e1 = hipMemcpy(base + o_info, rowinfo.data(), 16 * (size_t)n_rows, hipMemcpyHostToDevice);
+        if (e1 == hipSuccess && n_info) e1 = hipMemcpy(base + o_info, rowinfo.data(), 16 * n_info, hipMemcpyHostToDevice);
         if (e1 == hipSuccess && n_long) {
-            e1 = hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice);
-            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_ptr, chunk_ptr.data(), 4 * (n_long + 1), hipMemcpyHostToDevice);
-            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_own, owner.data(), 4 * n_chunks, hipMemcpyHostToDevice);
+            e1 = hipMemcpy(base + o_chk, chunks.data(), 16 * n_slots, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_nch, long_nch.data(), 4 * n_long, hipMemcpyHostToDevice);
         }
-        if (e1 != hipSuccess) { (void)hipFree(base); delete g; lgcn_set_error("lgcn_graph_create: plan upload failed"); return 10; }
+        if (e1 != hipSuccess) { (void)hipFree(base); (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: plan upload failed"); return 10; }
         g->rowinfo = (const int4 *)(base + o_info);
         if (n_long) {
-            g->lp.long_row = (const int32_t *)(base + o_row); g->lp.chunk_ptr = (const int32_t *)(base + o_ptr);
-            g->lp.chunk_owner = (const int32_t *)(base + o_own); g->lp.counters = (int32_t *)(base + o_cnt);
+            g->lp.chunks = (const int4 *)(base + o_chk);
+            g->lp.long_row = (const int32_t *)(base + o_row); g->lp.long_nch = (const int32_t *)(base + o_nch);
+            g->lp.counters = (int32_t *)(base + o_cnt);
             g->lp.partials = (float *)(base + o_par);
-            g->lp.n_long = (int32_t)n_long; g->lp.n_chunks = (int32_t)n_chunks;
+            g->lp.n_long = (int32_t)n_long; g->lp.n_chunk_slots = (int32_t)n_slots;
         }
     }
     *out = g;
@@ -838,12 +1003,13 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
 extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
     if (!g) return;
     if (g->owned) (void)hipFree(g->owned);
+    if (g->order_ev) (void)hipEventDestroy(g->order_ev);
     delete g;
 }
 
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.indptr = g->indptr; a.indices = g->indices; a.vals = g->vals; a.rowinfo = g->rowinfo; a.n_rows = g->n_rows; a.lp = g->lp;
+    a.indices = g->indices; a.vals = g->vals; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp;
     return a;
 }
 
@@ -853,7 +1019,9 @@ extern "C" int lgcn_spmm_csr(const lgcn_graph *g, const void *X, int x_dtype, vo
     if (d > g->d_max) { lgcn_set_error("lgcn_spmm_csr: d exceeds the graph's d_max"); return 3; }
     SpmmArgs a = graph_spmm(g);
     a.X = X; a.Y = Y; a.remap = 1;
-    int rc = launch_spmm<0>(a, d, x_dtype, y_dtype, (hipStream_t)stream);
+    int rc = graph_acquire(g, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = launch_spmm<0>(a, d, x_dtype, y_dtype, (hipStream_t)stream);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
     return 0;
@@ -868,6 +1036,7 @@ extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, 
     if (check_dtype(act_dtype)) return 3;
     if (d > g->d_max) { lgcn_set_error("lgcn_propagate_mean: d exceeds the graph's d_max"); return 3; }
     hipStream_t st = (hipStream_t)stream;
+    { int rc0 = graph_acquire(g, st); if (rc0) return rc0; }
     const int64_t N = g->n_rows;
     MeanArgs m{};
     m.X0 = E0; m.K = K; m.out = out; m.n4 = N * d / 4;
@@ -948,6 +1117,7 @@ static SpmmArgs base_spmm(const lgcn_ctx *x) {
 // forward layers X_1..X_{K-1}
 static int run_forward(lgcn_ctx *x, hipStream_t st) {
     const lgcn_train_config &c = x->c;
+    { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     const void *prev = c.E0; int prev_dt = LGCN_F32;
     for (int k = 1; k < c.K; k++) {
         SpmmArgs a = base_spmm(x);
@@ -974,7 +1144,12 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
     a.terms_off = atomics ? b_off : 0; a.terms_stride = B_global;
     a.ebuf = c.ebuf;
-    if (B_local <= 0) return 0;
+    if (B_local <= 0) {
+        // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
+        // two steps ago still has to be cleared (k_bpr_loss does it on the other ranks)
+        HIP_OK(hipMemsetAsync(a.stale_bitmap, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
+        return 0;
+    }
     DISPATCH_D(c.d, {
         if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
         else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
@@ -988,6 +1163,7 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
 static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
                         const float *gathered, int32_t shard, int32_t world, float *loss_out, hipStream_t st) {
     const lgcn_train_config &c = x->c;
+    { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
     s.G64 = (long long *)c.G64; s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
@@ -1020,8 +1196,8 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
             }
         }
         int rc;
-        if (first && last) rc = launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
-        else if (first) rc = launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
+        if (first && last) rc = launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st, x->bm_words);
+        else if (first) rc = launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st, x->bm_words);
         else if (last) rc = launch_spmm<M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
         else rc = launch_spmm<M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
         if (rc) return rc;

@@ -87,9 +87,12 @@ class Loader(BasicDataset):
                                                 _lib.npp(indices), _lib.npp(vals), _lib.npp(nnz)),
                    "lgcn_build_user_item_csr")
         self._r_indices, self._r_vals = indices[:int(nnz[0])], vals[:int(nnz[0])]
+        self._finish_init()
+
+    def _finish_init(self):
+        """Everything dataloader.py:133-150 derives from the user-item CSR."""
         self.UserItemNet = sp.csr_matrix((self._r_vals, self._r_indices, self._r_indptr),
                                          shape=(self.n_user, self.m_item))
-
         self.users_D = np.array(self.UserItemNet.sum(axis=1)).squeeze()
         self.users_D[self.users_D == 0.] = 1.
         self.items_D = np.array(self.UserItemNet.sum(axis=0)).squeeze()
@@ -172,8 +175,10 @@ class Loader(BasicDataset):
         HIP kernels consume; loaded from / saved to the reference's s_pre_adj_mat.npz."""
         if self._norm_adj is not None:
             return self._norm_adj
-        pre_adj_path = join(self.path, 's_pre_adj_mat.npz')
+        pre_adj_path = join(self.path, 's_pre_adj_mat.npz') if self.path else None
         try:
+            if pre_adj_path is None:
+                raise FileNotFoundError
             norm_adj = sp.load_npz(pre_adj_path).tocsr()
             norm_adj.sort_indices()
             print("successfully loaded...")
@@ -183,7 +188,8 @@ class Loader(BasicDataset):
             norm_adj = self._build_norm_adj()
             print(f"costing {time() - s:.2f}s, saved norm_mat...")
             try:
-                sp.save_npz(pre_adj_path, norm_adj)
+                if pre_adj_path is not None:
+                    sp.save_npz(pre_adj_path, norm_adj)
             except OSError as e:                     # read-only dataset dir
                 warnings.warn(f"could not cache {pre_adj_path}: {e}")
         if norm_adj.indices.dtype != np.int32 or norm_adj.indptr.dtype != np.int32:
@@ -213,3 +219,32 @@ class Loader(BasicDataset):
 
     def __len__(self):
         return len(self.trainUniqueUsers)
+
+
+class CsrLoader(Loader):
+    """NEW: the same dataset object built straight from the user-item CSR (int64 indptr
+    [n_users+1], int32 indices sorted + unique per row) instead of train.txt/test.txt -- what the
+    synthetic workloads (synthetic.py) and a caller that already holds the interactions in memory
+    use.  Nothing is read from or written to disk unless `path` is given."""
+
+    def __init__(self, indptr, indices, m_items, test_dict=None, config=world.config, path=None):
+        self.path = path
+        self.split = config.get('A_split', False)
+        self.folds = config.get('A_n_fold', 100)
+        self._r_indptr = np.ascontiguousarray(indptr, np.int64)
+        self._r_indices = np.ascontiguousarray(indices, np.int32)
+        if self._r_indptr[0] != 0 or self._r_indptr[-1] != len(self._r_indices) or np.any(np.diff(self._r_indptr) < 0):
+            raise ValueError("CsrLoader: indptr does not describe indices")
+        if len(self._r_indices) and (self._r_indices.min() < 0 or self._r_indices.max() >= m_items):
+            raise ValueError("CsrLoader: item id out of range")
+        self._r_vals = np.ones(len(self._r_indices), np.float32)
+        self.n_user, self.m_item = len(self._r_indptr) - 1, int(m_items)
+        self.traindataSize = len(self._r_indices)
+        self.trainUniqueUsers = np.flatnonzero(np.diff(self._r_indptr) > 0).astype(np.int64)
+        self.trainUser = self.trainItem = None            # the COO lists are not materialised
+        td = dict(test_dict or {})
+        self.testUser = np.fromiter((u for u, its in td.items() for _ in its), dtype=np.int64)
+        self.testItem = np.fromiter((i for its in td.values() for i in its), dtype=np.int64)
+        self.testUniqueUsers = np.fromiter(td.keys(), dtype=np.int64, count=len(td))
+        self.testDataSize = len(self.testUser)
+        self._finish_init()

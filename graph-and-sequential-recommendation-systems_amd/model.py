@@ -158,13 +158,13 @@ class LightGCN(nn.Module):
         if self._dev is None:
             a = self._adj
             from . import reorder
-            order = reorder.row_order(self.config.get('row_order', 'natural'), self.dataset, a,
-                                      cache_dir=getattr(self.dataset, 'path', None))
+            order, xcd_start = reorder.row_order(self.config.get('row_order', 'natural'), self.dataset, a,
+                                                 cache_dir=getattr(self.dataset, 'path', None))
             self._dev = {
                 'graph': _lib.Graph(torch.from_numpy(np.ascontiguousarray(a.indptr, np.int32)).to(dev),
                                     torch.from_numpy(np.ascontiguousarray(a.indices, np.int32)).to(dev),
                                     torch.from_numpy(np.ascontiguousarray(a.data, np.float32)).to(dev),
-                                    d_max=self.latent_dim, row_order=order),
+                                    d_max=self.latent_dim, row_order=order, xcd_start=xcd_start),
                 'ctx': None, 'max_batch': 0,
             }
         st = self._dev

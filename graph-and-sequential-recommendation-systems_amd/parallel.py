@@ -55,7 +55,7 @@ class DataParallelBPR:
     """Drop-in for utils.BPRLoss when torch.distributed is initialised: same
     `stageOne(users, pos, neg)` on the GLOBAL batch (identical on every rank)."""
 
-    def __init__(self, recmodel, config, group=None, reduce='rows'):
+    def __init__(self, recmodel, config, group=None, reduce='rows', shard='batch'):
         from .utils import _AdamView
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -71,8 +71,25 @@ class DataParallelBPR:
         if reduce not in ('rows', 'dense'):
             raise ValueError("reduce must be 'rows' (all-gather of gradient rows) or 'dense' (all-reduce of the table)")
         self.reduce = reduce
+        if shard not in ('batch', 'rows'):
+            raise ValueError("shard must be 'batch' (replicated propagation) or 'rows' (row-sharded propagation)")
+        if shard == 'rows':
+            raise NotImplementedError("row-sharded propagation is not built yet")
+        self.shard = shard
 
     def stageOne(self, users, pos, neg):
+        loss = self._step(users, pos, neg)
+        return loss[0] if self.lazy else loss[0].cpu().item()
+
+    def train_epoch(self, users, pos, neg, global_batch):
+        """The loop of main.py:223-225 over already-shuffled device id arrays (identical on every
+        rank): consecutive global batches, last one short.  -> device tensor [steps, 3]."""
+        T = int(users.numel())
+        out = [self._step(users[t:t + global_batch], pos[t:t + global_batch], neg[t:t + global_batch])
+               for t in range(0, T, global_batch)]
+        return torch.stack(out)
+
+    def _step(self, users, pos, neg):
         m = self.model
         dev = m._table.device
         users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)
@@ -100,4 +117,4 @@ class DataParallelBPR:
                                                 self.world, gptr, _lib.tp(loss), stream),
                    "lgcn_train_step_dp_part2")
         m._cache = None
-        return loss[0] if self.lazy else loss[0].cpu().item()
+        return loss

@@ -62,7 +62,7 @@ def build_parser():
                    help='NEW: storage type of propagated layer activations (accumulation is fp32)')
     p.add_argument('--xcd_remap', type=int, default=1,
                    help='NEW: give every XCD a contiguous range of graph rows')
-    p.add_argument('--row_order', type=str, default='cocluster', choices=['natural', 'rcm', 'cocluster'],
+    p.add_argument('--row_order', type=str, default='xcd', choices=['natural', 'rcm', 'cocluster', 'xcd'],
                    help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
     p.add_argument('--prefetch_epoch', type=int, default=0,
                    help='NEW: 1 = sample/shuffle/upload epoch e+1 while epoch e runs on the GPU')

@@ -103,8 +103,22 @@ def configure(argv=None):
     return config
 
 
+def _argv_is_foreign():
+    """sys.argv belongs to another program (a test runner, an embedding application) rather than to
+    a training launch: only then may an unparsable argv fall back to the defaults."""
+    if os.environ.get('LGCN_LENIENT_ARGV') == '1' or 'pytest' in sys.modules or 'sphinx' in sys.modules:
+        return True
+    prog = os.path.basename(sys.argv[0]) if sys.argv and sys.argv[0] else ''
+    return prog in ('', '-c', '-m', 'ipython', 'ipykernel_launcher.py') or prog.startswith('pytest')
+
+
 try:
     configure(None if len(sys.argv) > 0 else [])
-except SystemExit as _e:           # argv belongs to someone else (pytest, a launcher)
+except SystemExit as _e:
+    # The reference exits on a bad flag (world.py:26 -> argparse).  So does this module when it is
+    # imported by a training entry point: training on silently substituted defaults is worse.
+    if not _argv_is_foreign():
+        raise
     ARGV_ERROR = f"sys.argv not understood by parse.py (exit {_e.code}); defaults used"
+    cprint("[world] " + ARGV_ERROR)
     configure([])

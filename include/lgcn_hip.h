@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 1
+#define LGCN_ABI_VERSION 2
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -96,14 +96,18 @@ int lgcn_build_norm_adj(int n_users, int m_items, const int64_t *r_indptr, const
  * here as CSR: int32 indptr[n_rows+1], int32 indices[nnz] sorted per row, fp32 vals[nnz]).
  * The arrays are borrowed (must outlive the graph).  Creation is synchronous: it reads
  * indptr back once to plan the splitting of long rows and allocates that plan's scratch
- * (d_max = largest embedding dim that will be used with this graph).  One launch at a
- * time per graph (the scratch is shared).  row_order (device int32[n_rows], may be NULL)
- * is an optional PROCESSING order of the rows -- a permutation chosen for L2 locality;
- * it changes neither the memory layout nor any result bit.                             */
+ * (d_max = largest embedding dim that will be used with this graph).  Column indices are
+ * range-checked here (rc 3), so no later launch can gather out of bounds.  Launches on one
+ * graph share its scratch: the library orders them (a launch on another stream than the
+ * previous one first waits for it).
+ * row_order (DEVICE int32[n_rows], may be NULL) is an optional PROCESSING order of the rows
+ * -- a permutation chosen for L2 locality; xcd_start (HOST int64[9], may be NULL) cuts that
+ * order into the 8 slices the 8 XCDs work on (NULL: 8 slices of equal work).  Neither
+ * changes the memory layout or any result bit.                                          */
 typedef struct lgcn_graph lgcn_graph;   /* opaque */
 int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                       int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                      lgcn_graph **out);
+                      const int64_t *xcd_start, lgcn_graph **out);
 void lgcn_graph_destroy(lgcn_graph *g);
 
 /* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217

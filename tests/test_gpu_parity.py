@@ -497,14 +497,16 @@ def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
 
 @pytest.mark.parametrize("d", [32, 64, 128, 256])
 def test_spmm_row_length_boundaries(pkg, oracle, d):
-    """Row lengths on both sides of every internal boundary of the SpMM kernel: the 64-entry index
-    tile (short-row path), the one-chunk rows (65..128) and the multi-chunk rows that go through
-    the partial-row hand-off (129, 256, 257, 1000), plus empty rows, in every position of the
-    4-rows-per-wave / 4-waves-per-workgroup tiling."""
+    """Row lengths on both sides of every internal boundary of the SpMM kernel, derived from its
+    constants LONG_T = 64 (one index tile: the short-row path) and LONG_CH = 512 (one chunk): rows of
+    65..512 non-zeros are finished by one wave, 513.. go through the partial-row hand-off with 2, 3 and
+    4 chunks (1023/1024/1025, 1537), plus empty rows, in every position of the 4-rows-per-wave /
+    4-waves-per-workgroup tiling, for the natural order, a random order and a random order with an
+    explicit (deliberately uneven) XCD cut."""
     rng = np.random.Generator(np.random.PCG64(100 + d))
     lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193,
-            255, 256, 257, 511, 1000, 0, 64, 65, 128, 129, 7, 7, 7]
-    n = 1200
+            255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025, 1537, 0, 64, 65, 512, 513, 7, 7, 7]
+    n = 1600
     deg = np.array([lens[i % len(lens)] for i in range(n)], np.int64)
     deg = deg[rng.permutation(n)]
     indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
@@ -512,11 +514,153 @@ def test_spmm_row_length_boundaries(pkg, oracle, d):
     vals = rng.uniform(0.01, 0.4, len(indices)).astype(np.float32)
     X = rng.normal(0, 0.1, (n, d)).astype(np.float32)
     ref = oracle.spmm(indptr, indices, vals, X)
-    for order in (None, rng.permutation(n).astype(np.int32)):
-        g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order)
+    first = None
+    cut = np.array([0, 10, 10, 300, 700, 701, 1200, 1599, 1600], np.int64)
+    for order, xs in ((None, None), (rng.permutation(n).astype(np.int32), None), (rng.permutation(n).astype(np.int32), cut)):
+        g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order, xcd_start=xs)
         got = g.spmm(_dev(X)).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
-        again = g.spmm(_dev(X)).cpu().numpy()          # counters of the hand-off are reset: second launch identical
-        assert np.array_equal(got.view(np.uint32), again.view(np.uint32))
+        again = g.spmm(_dev(2.0 * X)).cpu().numpy()    # other data through the same scratch: tickets were reset, no stale partial
+        np.testing.assert_allclose(again, 2.0 * ref, rtol=2e-5, atol=2e-6)
+        third = g.spmm(_dev(X)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), third.view(np.uint32))
+        if first is None:
+            first = got
+        assert np.array_equal(first.view(np.uint32), got.view(np.uint32))      # order / XCD cut change no bit
         g.close()
     assert np.array_equal(got[deg == 0], np.zeros_like(got[deg == 0]))
+    with pytest.raises(pkg._lib.LgcnError):
+        pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, xcd_start=np.array([0, 5, 4, 9, 9, 9, 9, 9, n]))
+    bad = indices.copy(); bad[3] = n
+    with pytest.raises(pkg._lib.LgcnError, match="column index"):
+        pkg._lib.Graph(_dev(indptr), _dev(bad), _dev(vals), d_max=d)
+    g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d)
+    with pytest.raises(pkg._lib.LgcnError):
+        g.spmm(_dev(X[:-1]))                                                       # short X
+    g.close()
+
+
+@pytest.mark.parametrize("d,bf16", [(64, False), (64, True), (128, False), (256, True), (32, False)])
+def test_spmm_hub_rows_forty_chunks(pkg, oracle, d, bf16):
+    """Heavy-tail rows (the synthetic Yelp/Amazon shapes have 19-45-chunk rows): rows of 20 500 and
+    9 700 non-zeros = 41 and 19 chunks of 512 whose partial rows meet through the write-through
+    hand-off on different XCDs, checked against the oracle with DIFFERENT data on every launch (a
+    stale or missed partial cannot hide behind identical values), 6 launches back to back."""
+    rng = np.random.Generator(np.random.PCG64(7 + d))
+    n = 24000
+    deg = rng.poisson(6, n).astype(np.int64)
+    deg[[5, 11000, 23999]] = [20500, 9700, 513]
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in deg]).astype(np.int32)
+    vals = rng.uniform(0.001, 0.05, len(indices)).astype(np.float32)
+    g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=rng.permutation(n).astype(np.int32))
+    for it in range(6):
+        X = rng.normal(0, 0.1, (n, d)).astype(np.float32)
+        x = _dev(X)
+        if bf16:
+            x = x.to(torch.bfloat16)
+            X = x.float().cpu().numpy()
+        got = g.spmm(x, 0).cpu().numpy()
+        ref = oracle.spmm(indptr, indices, vals, X)
+        np.testing.assert_allclose(got, ref, rtol=3e-5, atol=2e-6, err_msg=f"launch {it}")
+    g.close()
+
+
+def _synthetic_model(pkg, name, act="fp32", row_order="xcd"):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n_users, m_items, E, K, d, B = bench.WORKLOADS[name][:6]
+    w = pkg.world
+    w.configure(["--dataset", name, "--tensorboard", "0", "--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B),
+                 "--act_dtype", act, "--row_order", row_order])
+    ds = bench.synthetic_dataset(pkg, name, w.config, DEV)
+    pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    return ds, m, K, d, B
+
+
+@pytest.mark.parametrize("name", ["yelp2018-shaped", "amazon-book-shaped"])
+def test_full_shape_synthetic_configs_vs_oracle(pkg, oracle, name):
+    """BASELINE configs[2] (Yelp2018 shape: 31 668 x 38 048, E = 1 237 259, K = 3, d = 64, B = 8192) and
+    configs[3] (Amazon-Book shape: 52 643 x 91 599, E = 2 380 730, K = 4, d = 128, B = 2048) at FULL
+    size on the seeded synthetic graph (the real train splits are absent from the reference checkout):
+    native sampler triplets, 3 fused steps vs the oracle's stageOne (loss 5e-6, parameters 1e-5), the
+    propagated table vs the oracle, a second identical run bit for bit, and the data-parallel split
+    (world = 2, 4, 8 emulated on one GPU) bit for bit.  These graphs have 19-45-chunk hub rows."""
+    ds, m, K, d, B = _synthetic_model(pkg, name)
+    adj = ds.getSparseGraphCSR()
+    assert np.diff(adj.indptr).max() > 19 * 512
+    e0 = m._table.cpu().numpy().copy()
+    S = pkg.utils.UniformSample_original(ds)[:3 * B]
+    assert S.shape == (3 * B, 3) and S.dtype == np.int32
+    tr = oracle.Trainer(ds.n_users, adj.indptr, adj.indices, adj.data, e0, K, pkg.world.config['decay'], pkg.world.config['lr'])
+    batches = [tuple(_dev(np.ascontiguousarray(S[i * B:(i + 1) * B, c]), torch.int32) for c in range(3)) for i in range(3)]
+    losses = []
+    for i, (u, p, n) in enumerate(batches):
+        l_ref = tr.stageOne(S[i * B:(i + 1) * B, 0], S[i * B:(i + 1) * B, 1], S[i * B:(i + 1) * B, 2])
+        l_got = m.fused_step(u, p, n).cpu().numpy()
+        losses.append(l_got.copy())
+        assert abs(float(l_got[0]) - l_ref) < 5e-6, (i, l_got, l_ref)
+        np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=1e-5)
+    with torch.no_grad():
+        au, ai = m.computer()
+    ref = oracle.propagate(adj.indptr, adj.indices, adj.data, tr.e0, K)
+    np.testing.assert_allclose(torch.cat([au, ai]).cpu().numpy(), ref, rtol=3e-5, atol=3e-7)
+    m.check_device_errors()
+    want = m._table.cpu().numpy().copy()
+
+    L, lib = pkg._lib, pkg._lib.load()
+    for world in (1, 2, 4, 8):
+        ds2, m2, *_ = _synthetic_model(pkg, name)
+        assert np.array_equal(m2._table.cpu().numpy(), e0)
+        for i, (u, p, n) in enumerate(batches):
+            if world == 1:
+                out = m2.fused_step(u, p, n)
+            else:
+                st = m2._state(max_batch=B, need_ctx=True, dp_world=world)
+                nblk = pkg.parallel.block_numel(B, world, d)
+                blocks = []
+                for r in range(world):
+                    L.check(lib.lgcn_train_step_dp_part1(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, r, L.current_stream()), "part1")
+                    blocks.append(st['contrib'][:nblk].clone())
+                out = torch.empty(3, device=DEV)
+                L.check(lib.lgcn_train_step_dp_part2(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, L.tp(torch.cat(blocks)),
+                                                     L.tp(out), L.current_stream()), "part2")
+            np.testing.assert_allclose(out.cpu().numpy(), losses[i], rtol=0, atol=1e-6)
+        assert np.array_equal(m2._table.cpu().numpy().view(np.uint32), want.view(np.uint32)), world
+        del m2, ds2
+
+
+def test_dp_empty_trailing_shard(pkg, tiny, tmp_path):
+    """A short last batch can leave trailing ranks without triplets (B = 2 on 3 ranks: shard 1, rank 2
+    empty).  Such a rank launches no BPR kernel but must still clear the row bitmap of two steps ago;
+    its tables and bitmaps stay identical to the other ranks' and to the single-GPU run."""
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(4))
+    batches = [(rng.integers(0, g.n_users, b), rng.integers(0, g.m_items, b), rng.integers(0, g.m_items, b)) for b in (64, 64, 2, 2)]
+    L, lib = pkg._lib, pkg._lib.load()
+    ds, ref = _make_model(pkg, g, tmp_path)
+    for (u, p, n) in batches:
+        ref.fused_step(_dev(u, torch.int32), _dev(p, torch.int32), _dev(n, torch.int32))
+    world = 3
+    ranks = [_make_model(pkg, g, tmp_path)[1] for _ in range(world)]
+    for (u, p, n) in batches:
+        u, p, n = (_dev(x, torch.int32) for x in (u, p, n))
+        B = len(u)
+        nblk = pkg.parallel.block_numel(B, world, g.d)
+        sts = [m._state(max_batch=64, need_ctx=True, dp_world=world) for m in ranks]
+        blocks = []
+        for r, st in enumerate(sts):
+            L.check(lib.lgcn_train_step_dp_part1(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, r, L.current_stream()), "part1")
+            blocks.append(st['contrib'][:nblk].clone() if r * pkg.parallel.shard_size(B, world) < B else torch.zeros(nblk, device=DEV))
+        gathered = torch.cat(blocks)
+        for st in sts:
+            out = torch.empty(3, device=DEV)
+            L.check(lib.lgcn_train_step_dp_part2(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, L.tp(gathered), L.tp(out),
+                                                 L.current_stream()), "part2")
+    torch.cuda.synchronize()
+    for m in ranks:
+        assert np.array_equal(m._table.cpu().numpy().view(np.uint32), ref._table.cpu().numpy().view(np.uint32))
+        assert torch.equal(m._dev['bitmap'], ranks[0]._dev['bitmap'])
+        assert int(m._dev['G64'].abs().sum()) == 0

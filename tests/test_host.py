@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(pkg._lib.SIGNATURES) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lgcn_abi_version() == 1
+    assert lib.lgcn_abi_version() == 2
     assert lib.lgcn_device_available() in (0, 1)
 
 
@@ -244,14 +244,47 @@ def test_row_orders_are_permutations(pkg, tiny, lastfm, tmp_path):
         ds = _load(pkg, g, tmp_path)
         adj = ds.getSparseGraphCSR()
         N = g.n_users + g.m_items
-        assert pkg.reorder.row_order('natural', ds, adj) is None
-        for method in ('rcm', 'cocluster'):
-            o = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)
+        assert pkg.reorder.row_order('natural', ds, adj) == (None, None)
+        for method in ('rcm', 'cocluster', 'xcd'):
+            o, xs = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)
             assert o.dtype == np.int32 and np.array_equal(np.sort(o), np.arange(N)), method
-            assert os.path.exists(os.path.join(ds.path, f"s_row_order_{method}.npy"))
-            assert np.array_equal(o, pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path))   # cached
+            assert os.path.exists(os.path.join(ds.path, f"s_row_order_{method}.npz"))
+            o2, xs2 = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)                    # cached
+            assert np.array_equal(o, o2)
+            if method == 'xcd':      # the 8 XCD slices: a monotone cut of the order, balanced by non-zeros
+                assert xs.dtype == np.int64 and xs.shape == (9,) and xs[0] == 0 and xs[-1] == N
+                assert np.all(np.diff(xs) >= 0) and np.array_equal(xs, xs2)
+                if g is lastfm:
+                    w = np.diff(adj.indptr)[o]
+                    per = np.array([w[xs[x]:xs[x + 1]].sum() for x in range(8)], np.float64)
+                    assert per.max() < 1.25 * per.mean(), per
+            else:
+                assert xs is None and xs2 is None
     with pytest.raises(ValueError):
         pkg.reorder.row_order('bogus', ds, adj)
+
+
+def test_synthetic_generator_and_csr_loader(pkg):
+    """The vectorised generator behind the BASELINE configs[2..4] shapes: exact E, every user >= 1 item,
+    sorted unique columns, seeded; CsrLoader builds the same dataset object the text Loader does."""
+    ip, ix = pkg.synthetic.power_law_bipartite(3000, 2000, 40000, seed=5, device="cpu")
+    ip2, ix2 = pkg.synthetic.power_law_bipartite(3000, 2000, 40000, seed=5, device="cpu")
+    assert np.array_equal(ip, ip2) and np.array_equal(ix, ix2)
+    deg = np.diff(ip)
+    assert ip[-1] == 40000 and len(ix) == 40000 and deg.min() >= 1 and deg.max() <= 2000 // 4
+    key = np.repeat(np.arange(3000, dtype=np.int64), deg) * 2000 + ix
+    assert np.all(np.diff(key) > 0)                                   # sorted, no duplicates
+    assert np.bincount(ix, minlength=2000).max() > 20 * 40000 / 2000   # heavy-tailed item popularity
+    pkg.world.configure([])
+    ds = pkg.dataloader.CsrLoader(ip, ix, 2000, test_dict={0: [1, 2], 5: [3]}, config=pkg.world.config)
+    assert (ds.n_users, ds.m_items, ds.trainDataSize) == (3000, 2000, 40000)
+    assert np.array_equal(ds.allPos[7], ix[ip[7]:ip[8]]) and ds.testDict == {0: [1, 2], 5: [3]}
+    adj = ds.getSparseGraphCSR()
+    from oracle import oracle as orc
+    oip, oix, odata, _ = orc.build_norm_adj(3000, 2000, ip, ix, np.ones(40000, np.float32))
+    assert np.array_equal(adj.indptr, oip) and np.array_equal(adj.indices, oix) and np.array_equal(adj.data, odata)
+    with pytest.raises(ValueError):
+        pkg.dataloader.CsrLoader(ip, ix, 1000, config=pkg.world.config)          # item id out of range
 
 
 def test_user_item_csr_matches_scipy_on_random_inputs(pkg):
