@@ -63,6 +63,13 @@ SIGNATURES = {
     "lgcn_train_step_dp_dense_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
+    "lgcn_dp_available": (C.c_int, []),
+    "lgcn_dp_unique_id": (C.c_int, [_vp]),
+    "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lgcn_dp_destroy": (None, [_vp]),
+    "lgcn_dp_world": (C.c_int, [_vp]),
+    "lgcn_dp_rank": (C.c_int, [_vp]),
+    "lgcn_train_epoch_dp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
 }
 
 _LIB = None

@@ -28,8 +28,7 @@
 #include <vector>
 
 #include "lgcn_hip.h"
-
-extern "C" void lgcn_set_error(const char *msg);   // lgcn_host.cpp
+#include "lgcn_internal.h"
 
 #define HIP_OK(expr)                                                            \
     do {                                                                        \
@@ -1289,6 +1288,41 @@ extern "C" int lgcn_train_step_dp_part2(lgcn_ctx *x, const int32_t *users, const
     const int32_t shard = (B_global + world - 1) / world;
     if ((rc = run_backward(x, users, pos, neg, B_global, gathered, shard, world, loss_out, (hipStream_t)stream))) return rc;
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// A whole data-parallel epoch from ONE host call: per global batch, part 1 -> RCCL collective on the
+// SAME stream (no host synchronisation, no Python between the kernels and the collective) -> part 2.
+extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                                   int64_t T, int32_t B_global, int32_t reduce, float *gathered, float *loss_out,
+                                   void *stream) {
+    if (!x || !dp || !users || !pos || !neg || !loss_out) { lgcn_set_error("lgcn_train_epoch_dp: null argument"); return 3; }
+    if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE) { lgcn_set_error("lgcn_train_epoch_dp: reduce must be LGCN_DP_ROWS or LGCN_DP_DENSE"); return 3; }
+    if (reduce == LGCN_DP_ROWS && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
+    if (B_global <= 0 || B_global > x->c.max_batch) { lgcn_set_error("lgcn_train_epoch_dp: batch size out of range"); return 3; }
+    const RcclApi *api = lgcn_rccl();
+    if (!api) return 12;
+    hipStream_t st = (hipStream_t)stream;
+    const int world = dp->world, rank = dp->rank;
+    int64_t i = 0;
+    for (int64_t t = 0; t < T; t += B_global, i++) {
+        const int32_t b = (int32_t)((T - t) < B_global ? (T - t) : B_global);
+        int rc;
+        ncclResult_t r;
+        if (reduce == LGCN_DP_ROWS) {
+            if ((rc = lgcn_train_step_dp_part1(x, users + t, pos + t, neg + t, b, world, rank, stream))) return rc;
+            const int64_t S = (b + world - 1) / world, blk = 3 * S * x->c.d + 2 * S;
+            r = api->AllGather(x->c.contrib, gathered, (size_t)blk, ncclFloat32, dp->comm, st);
+            if (r != ncclSuccess) { lgcn_set_error("ncclAllGather failed"); return 11; }
+            if ((rc = lgcn_train_step_dp_part2(x, users + t, pos + t, neg + t, b, world, gathered, loss_out + 3 * i, stream))) return rc;
+        } else {
+            if ((rc = lgcn_train_step_dp_dense_part1(x, users + t, pos + t, neg + t, b, world, rank, stream))) return rc;
+            r = api->AllReduce(x->c.G64, x->c.G64, (size_t)x->N * x->c.d, ncclInt64, ncclSum, dp->comm, st);
+            if (r == ncclSuccess) r = api->AllReduce(x->c.terms, x->c.terms, (size_t)2 * b, ncclFloat32, ncclSum, dp->comm, st);
+            if (r != ncclSuccess) { lgcn_set_error("ncclAllReduce failed"); return 11; }
+            if ((rc = lgcn_train_step_dp_part2(x, users + t, pos + t, neg + t, b, world, nullptr, loss_out + 3 * i, stream))) return rc;
+        }
+    }
     return 0;
 }
 

@@ -20,6 +20,10 @@ gradient table, here the fixed-point G64 [N,d] int64, plus SUM of the loss terms
 rank flags the rows of the whole batch itself) -- kept as an alternative: also bitwise exact, but N*d*8 bytes
 per step (Gowalla 36 MB) instead of 1.6 MB.
 """
+import ctypes as C
+import os
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -76,6 +80,36 @@ class DataParallelBPR:
         if shard == 'rows':
             raise NotImplementedError("row-sharded propagation is not built yet")
         self.shard = shard
+        self._comm = None          # lgcn_dp handle: the library's own RCCL communicator (lazy)
+        self._gathered = None
+
+    # -- the library's RCCL communicator: collectives are issued from C on the kernels' stream --------
+    def _communicator(self):
+        """Rank 0 draws the ncclUniqueId, torch.distributed carries the 128 bytes to the other
+        ranks, every rank joins.  Only on GPU tensors (the gloo/CPU tests use `exchange`)."""
+        if self._comm is None:
+            lib = _lib.load()
+            buf = (C.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(lib.lgcn_dp_unique_id(buf), "lgcn_dp_unique_id")
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                       group=self.group)
+            h = C.c_void_p()
+            _lib.check(lib.lgcn_dp_init(box[0], self.world, self.rank, C.byref(h)), "lgcn_dp_init")
+            self._comm = h
+        return self._comm
+
+    def close(self):
+        if self._comm is not None:
+            _lib.load().lgcn_dp_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stageOne(self, users, pos, neg):
         loss = self._step(users, pos, neg)
@@ -84,10 +118,30 @@ class DataParallelBPR:
     def train_epoch(self, users, pos, neg, global_batch):
         """The loop of main.py:223-225 over already-shuffled device id arrays (identical on every
         rank): consecutive global batches, last one short.  -> device tensor [steps, 3]."""
+        m = self.model
+        dev = m._table.device
         T = int(users.numel())
-        out = [self._step(users[t:t + global_batch], pos[t:t + global_batch], neg[t:t + global_batch])
-               for t in range(0, T, global_batch)]
-        return torch.stack(out)
+        if dev.type != 'cuda' or os.environ.get("LGCN_DP_PYTHON_LOOP") == "1":
+            out = [self._step(users[t:t + global_batch], pos[t:t + global_batch], neg[t:t + global_batch])
+                   for t in range(0, T, global_batch)]
+            return torch.stack(out)
+        # one host call per epoch: the C loop issues kernels and RCCL collectives on one stream
+        users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)
+        st = m._state(max_batch=max(int(global_batch), int(m.config.get('bpr_batch_size', global_batch))), need_ctx=True,
+                      dp_world=self.world)
+        lib = _lib.load()
+        lib.lgcn_ctx_set_lr(st['ctx'], float(self.opt.param_groups[0]['lr']))
+        steps = (T + global_batch - 1) // global_batch
+        losses = torch.empty(steps, 3, dtype=torch.float32, device=dev)
+        n = self.world * block_numel(global_batch, self.world, m.latent_dim)
+        if self.reduce == 'rows' and (self._gathered is None or self._gathered.numel() < n):
+            self._gathered = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.lgcn_train_epoch_dp(st['ctx'], self._communicator(), _lib.tp(users), _lib.tp(pos), _lib.tp(neg), T,
+                                           int(global_batch), 0 if self.reduce == 'rows' else 1,
+                                           _lib.tp(self._gathered) if self.reduce == 'rows' else None,
+                                           _lib.tp(losses), _lib.current_stream()), "lgcn_train_epoch_dp")
+        m._cache = None
+        return losses
 
     def _step(self, users, pos, neg):
         m = self.model

@@ -203,6 +203,31 @@ int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t 
                              const int32_t *neg, int32_t B_global, int32_t world,
                              const float *gathered, float *loss_out, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Data parallel over RCCL (no counterpart in the reference: SURVEY 2, north_star) */
+/* ------------------------------------------------------------------------ */
+/* RCCL is resolved at run time (dlopen of the librccl already mapped into the process, else
+ * $LGCN_RCCL_PATH, else the system one); the library itself does not link it.  One communicator
+ * per process / GPU.  Rank 0 creates the 128-byte id (ncclGetUniqueId) and the caller hands it to
+ * every rank through any channel it has (torch.distributed store, MPI, a file).             */
+#define LGCN_DP_ID_BYTES 128
+enum { LGCN_DP_ROWS = 0, LGCN_DP_DENSE = 1 };
+typedef struct lgcn_dp lgcn_dp;   /* opaque */
+int lgcn_dp_available(void);                         /* 1 if RCCL could be resolved */
+int lgcn_dp_unique_id(void *id128);
+int lgcn_dp_init(const void *id128, int world, int rank, lgcn_dp **out);   /* on the current HIP device */
+void lgcn_dp_destroy(lgcn_dp *dp);
+int lgcn_dp_world(const lgcn_dp *dp);
+int lgcn_dp_rank(const lgcn_dp *dp);
+/* A whole data-parallel epoch in one host call: the loop of main.py:223-225 over ceil(T/B_global)
+ * global batches (arrays identical on every rank); per batch: part 1, the collective on `stream`
+ * (reduce = LGCN_DP_ROWS: ncclAllGather of cfg.contrib blocks into `gathered`
+ * [world * (3*S*d + 2*S)] floats, S = ceil(B_global/world); LGCN_DP_DENSE: ncclAllReduce of G64 and
+ * of the loss terms, `gathered` unused), part 2.  No host synchronisation.  loss_out: [3*steps]. */
+int lgcn_train_epoch_dp(lgcn_ctx *ctx, lgcn_dp *dp, const int32_t *users, const int32_t *pos,
+                        const int32_t *neg, int64_t T, int32_t B_global, int32_t reduce,
+                        float *gathered, float *loss_out, void *stream);
+
 /* reads and clears the device error flag (synchronises the stream): 0 = none,
  * 1 = id out of range in users/pos/neg.                                        */
 int lgcn_ctx_check(lgcn_ctx *ctx, void *stream);

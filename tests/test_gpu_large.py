@@ -51,7 +51,8 @@ def test_nine_million_rows_dim256(pkg, oracle):
                                        rng.integers(0, N, 4096)]))
     ref_rows = _oracle_rows(oracle, A, X, sample)
     got_rows = Y[torch.from_numpy(sample).to(DEV)].cpu().numpy()
-    np.testing.assert_allclose(got_rows, ref_rows, rtol=2e-5, atol=1e-6)
+    # (the sample holds the 3000- and 700-term rows: partial sums reach ~1, so 5e-6 absolute)
+    np.testing.assert_allclose(got_rows, ref_rows, rtol=2e-5, atol=5e-6)
     At = torch.sparse_csr_tensor(ip.long(), ix.long(), vv, size=(N, N), device=DEV)
     Yref = torch.sparse.mm(At, X)
     err = float((Y - Yref).abs().max()); scale = float(Yref.abs().max())
