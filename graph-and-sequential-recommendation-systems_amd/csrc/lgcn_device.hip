@@ -24,6 +24,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <algorithm>
+#include <array>
 #include <new>
 #include <vector>
 
@@ -48,7 +50,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __bf16 bf16_t;
 
 #ifndef LGCN_GATHER_U
-#define LGCN_GATHER_U 4      /* max row gathers in flight per lane (8 needs > 64 VGPRs: fewer resident waves, slower) */
+#define LGCN_GATHER_U 8      /* max row gathers in flight per lane (8 x 16 B raw = 32 VGPRs) */
 #endif
 #define FIXED_SCALE 1125899906842624.0   /* 2^50 */
 #define FIXED_INV   8.8817841970012523e-16 /* 2^-50 */
@@ -199,7 +201,7 @@ __device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt,
 template <int D, typename TI, bool SPARSE>
 __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane,
                                             typename Geo<D, TI, SPARSE>::Acc &acc) {
-    constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 2 : LGCN_GATHER_U;
+    constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 4 : LGCN_GATHER_U;
 #ifdef LGCN_EXP_NO_GATHER
     return;
 #endif
@@ -283,12 +285,14 @@ row_gather(const int32_t *__restrict__ indices, const float *__restrict__ vals, 
 //     why the chunk is 512 and not one tile.  Long rows stay in the slice of their part of the
 //     graph: they are 29 % of Gowalla's non-zeros, and dealt round-robin over the XCDs (round 1)
 //     they alone produced half of the L2 misses.
-//   * the other rows go SPMM_RW per wave, 4 waves per workgroup, in order.
+//   * the other rows go NPW at a time per wave, ONE ROW PER LANE GROUP (NPW = 64 / lanes per row:
+//     4 fp32 rows or 8 bf16 rows at d = 64), 4 waves per workgroup, in order.  The plan sorts every
+//     window of SHORT_WIN consecutive short rows by length, so the rows of a pack are about equally
+//     long (the window is far smaller than what an XCD has in flight: locality is unaffected).
 // ---------------------------------------------------------------------------------
 #define LONG_T 64             /* rows with more non-zeros than one tile leave the short path */
-#ifndef SPMM_RW
-#define SPMM_RW 4            /* consecutive short rows per wave */
-#endif
+#define SLICE_PAD 64          /* short rows of a slice are padded to a multiple of this (>= rows per workgroup of every variant) */
+#define SHORT_WIN 512         /* window of the length sort */
 #ifndef LONG_CH
 #define LONG_CH 512           /* measured on Gowalla: 64 -> 58 us, 128 -> 40, 256 -> 34, 512 -> 32.5, 768 -> 39, none -> 57 */
 #endif
@@ -301,9 +305,9 @@ struct LongPlan {
     int32_t *counters;            // [n_long] arrival tickets (zero between launches)
     int32_t n_long, n_chunk_slots;
 };
-struct SlicePlan {                // per XCD slice x: chunk blocks [cblk[x], cblk[x+1]) then row tiles [tile[x], tile[x+1])
+struct SlicePlan {                // per XCD slice x: chunk blocks [cblk[x], cblk[x+1]) then short rows [rows[x], rows[x+1]) of rowinfo
     int32_t cblk[XCDS + 1];
-    int32_t tile[XCDS + 1];
+    int32_t rows[XCDS + 1];       // multiples of SLICE_PAD
 };
 
 struct SpmmArgs {
@@ -386,19 +390,26 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 // block of it): first the slice's long-row chunks, one per wave, then its short rows.
 //   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
 #ifndef SPMM_MIN_WAVES
-#define SPMM_MIN_WAVES 8      /* waves per SIMD the register allocation must allow (<= 64 VGPRs) */
+#define SPMM_MIN_WAVES 6      /* waves per SIMD the register allocation must allow (<= 80 VGPRs): a wave keeps up to
+                                 NPW x 8 row gathers in flight, so residency is not what hides the latency */
 #endif
-#ifndef SPMM_MIN_WAVES_BF16
-#define SPMM_MIN_WAVES_BF16 6 /* 8 columns per lane: 8-register accumulators and 4 x 16-byte raw pieces need <= 80 VGPRs */
+#ifndef SPMM_U
+#define SPMM_U 8              /* gathers in flight per lane in the short-row path */
 #endif
+// rows per workgroup of a kernel variant: 4 waves x PACKS packs x NPW rows
+template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= 4 ? 1 : 4 / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
+
 template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(256, (sizeof(TI) == 2 && !(MODE & M_SPARSE)) ? SPMM_MIN_WAVES_BF16 : SPMM_MIN_WAVES)
-k_spmm(SpmmArgs a) {
+__global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr bool SP = (MODE & M_SPARSE) != 0;
     typedef Geo<D, TI, SP> G;
     typedef typename G::Acc Acc;
+    typedef Raw<TI, SP> R;
     constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
-    __shared__ int2 stage_lds[4][64];
+    constexpr int PACKS = PackGeo<NPW>::PACKS, RPW = PackGeo<NPW>::RPW, RPB = PackGeo<NPW>::RPB;
+    constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
+    constexpr int U = SP ? 4 : SPMM_U;
+    __shared__ int2 stage_lds[4][NPW * ST];
     extern __shared__ uint32_t bm_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -420,14 +431,14 @@ k_spmm(SpmmArgs a) {
     else {        // slices as contiguous block ranges (placement-independent either way: speed only)
         x = 0; j = blockIdx.x;
         while (x < XCDS - 1) {
-            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.tile[x + 1] - a.sp.tile[x]);
+            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB;
             if (j < nb) break;
             j -= nb; x++;
         }
     }
     const int ncb = a.sp.cblk[x + 1] - a.sp.cblk[x];
     if (j < ncb) {
-        // ---- one chunk of a long row ----
+        // ---- one chunk of a long row, the whole wave on it ----
         const int c = (a.sp.cblk[x] + j) * 4 + wid;
         const int4 ch = a.lp.chunks[c];
         const int o = ch.x;
@@ -463,60 +474,73 @@ k_spmm(SpmmArgs a) {
         Acc tot = zerov<C>();
         for (int k = 0; k < nch; k++) {
             union { Acc v; unsigned long long q[C / 2]; } pk;
-            gu64 *s = (gu64 *)(a.lp.partials + (int64_t)(first + k) * D + lane * C);
+            gu64 *sp_ = (gu64 *)(a.lp.partials + (int64_t)(first + k) * D + lane * C);
 #pragma unroll
-            for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(sp_ + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k == 0) tot = pk.v; else tot += pk.v;
         }
         spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot);
         return;
     }
-    // ---- SPMM_RW short rows per wave, consecutive in the PROCESSING ORDER.  Rows are walked one
-    //      after the other; the index tile of row r+1 is in flight while row r gathers. ----
+    // ---- short rows (<= 64 non-zeros): a pack of NPW rows at a time, ONE ROW PER LANE GROUP.  All
+    //      index tiles of the pack are loaded back to back, then every group walks its own row U
+    //      gathers deep: NPW x U row gathers in flight per wave (32 at d = 64 fp32, 64 with a bf16
+    //      table) instead of one row's worth, no cross-group reduction, no divergence (the trip
+    //      count is the pack's longest row; shorter rows pad with zero-weight re-reads of their
+    //      last entry, and the plan sorts windows of rows by length so there is little to pad).
+    //      A row is summed in CSR order by one accumulator chain -- the reference's own order.
     const int t = j - ncb;
-    if (t >= a.sp.tile[x + 1] - a.sp.tile[x]) return;
-    const int64_t pos0 = ((int64_t)(a.sp.tile[x] + t) * 4 + wid) * SPMM_RW;
-    // lane r < SPMM_RW fetches (row id, first nnz, count) of its row with ONE 16-byte load from the
-    // plan (order -> indptr would be two dependent round trips); then wave-uniform registers
-    int my_row = -1, my_s = 0, my_n = 0;
-    if (lane < SPMM_RW) {
-        const int4 ri = a.rowinfo[pos0 + lane];
-        my_row = ri.x; my_s = ri.y; my_n = ri.z;
-    }
-    int rows[SPMM_RW], ip_s[SPMM_RW], ip_n[SPMM_RW];
-#pragma unroll
-    for (int r = 0; r < SPMM_RW; r++) {
-        rows[r] = __builtin_amdgcn_readlane(my_row, r);
-        ip_s[r] = __builtin_amdgcn_readlane(my_s, r); ip_n[r] = __builtin_amdgcn_readlane(my_n, r);
-    }
-    if (rows[0] < 0) return;                 // padding is at the end of a slice: nothing in this wave
-    int col_n = 0; float val_n = 0.f;
-    if (lane < ip_n[0]) { col_n = a.indices[ip_s[0] + lane]; val_n = a.vals[ip_s[0] + lane]; }
-    // Results are flushed every NPW rows: lane group g keeps the sum of row q+g, so an epilogue pass
-    // keeps all 64 lanes busy (an epilogue after every single row made the next row's staging wait
-    // for the store).
+    if (t >= (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB) return;
     const int g = lane / LPR, l = lane % LPR;
-    Acc mine = zerov<C>();
-    int mrow = -1;
+    int2 *stage = stage_lds[wid];
+#pragma unroll 1
+    for (int pk = 0; pk < PACKS; pk++) {
+        const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)t * RPB + (wid * PACKS + pk) * NPW;
+        // lane r < NPW fetches (row id, first nnz, count) of row r with ONE 16-byte load from the plan
+        int my_row = -1, my_s = 0, my_n = 0;
+        if (lane < NPW) {
+            const int4 ri = a.rowinfo[pos0 + lane];
+            my_row = ri.x; my_s = ri.y; my_n = ri.z;
+        }
+        if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
+        int colr[NPW]; float valr[NPW]; int nr[NPW];
 #pragma unroll
-    for (int r = 0; r < SPMM_RW; r++) {
-        const bool live = rows[r] >= 0;
-        int cnt = 0;
-        if (live) cnt = tile_stage<SP>(col_n, val_n, ip_n[r], src, lane, stage_lds[wid]);
-        __builtin_amdgcn_wave_barrier();
-        if (r + 1 < SPMM_RW) {          // first tile of the next row: in flight during this row's gathers
-            const int ns = ip_s[r + 1 < SPMM_RW ? r + 1 : r], nn = ip_n[r + 1 < SPMM_RW ? r + 1 : r];
-            if (lane < nn) { col_n = a.indices[ns + lane]; val_n = a.vals[ns + lane]; }
+        for (int r = 0; r < NPW; r++) {                              // all index tiles in flight together
+            const int s0 = __builtin_amdgcn_readlane(my_s, r);
+            nr[r] = __builtin_amdgcn_readlane(my_n, r);
+            colr[r] = 0; valr[r] = 0.f;
+            if (lane < nr[r]) { colr[r] = a.indices[s0 + lane]; valr[r] = a.vals[s0 + lane]; }
         }
+        int mycnt = 0, maxcnt = 0;
+#pragma unroll
+        for (int r = 0; r < NPW; r++) {
+            const int cnt = tile_stage<SP>(colr[r], valr[r], nr[r], src, lane, stage + r * ST);
+            if (cnt == 0 && lane == 0) stage[r * ST] = make_int2(0, 0);      // a valid column for the padding reads
+            if (g == r) mycnt = cnt;
+            maxcnt = max(maxcnt, cnt);
+        }
+        maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+        __builtin_amdgcn_wave_barrier();
+        const int2 *mystage = stage + g * ST;
+        const int last = max(mycnt - 1, 0);
         Acc acc = zerov<C>();
-        if (live) tile_gather<D, TI, SP>(stage_lds[wid], cnt, src, lane, acc);
-        __builtin_amdgcn_wave_barrier();
-        acc = reduce_groups<LPR>(acc);
-        if (g == r % NPW) { mine = acc; mrow = rows[r]; }
-        if (r % NPW == NPW - 1 || r == SPMM_RW - 1) {
-            if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, mine);
-            mrow = -1;
+        for (int u0 = 0; u0 < maxcnt; u0 += U) {
+            int2 cv[U]; typename R::T xr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = u0 + u;
+                cv[u] = mystage[min(e, last)];
+                if (e >= mycnt) cv[u].y = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) xr[u] = R::load(src, cv[u].x, D, l);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u], src.div);
         }
+        const int mrow = __shfl(my_row, g);
+        if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
+        if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -790,9 +814,11 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 #define BM_LDS_MAX_WORDS 4096     /* 16 KiB: with the 2 KiB stage, 8 workgroups still fit a CU's 160 KiB */
 template <int D, typename TI, typename TO, int MODE>
 static void launch_spmm_t(SpmmArgs a, int64_t bm_words, hipStream_t st) {
+    constexpr int RPB = PackGeo<Geo<D, TI, (MODE & M_SPARSE) != 0>::NPW>::RPB;
+    static_assert(SLICE_PAD % RPB == 0, "slice padding must hold whole workgroups of every variant");
     unsigned grid = 0, widest = 0;
     for (int x = 0; x < XCDS; x++) {
-        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.tile[x + 1] - a.sp.tile[x]));
+        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB);
         grid += nb; widest = nb > widest ? nb : widest;
     }
     if (a.remap) grid = widest * XCDS;
@@ -940,7 +966,8 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     SlicePlan sp{};
     rowinfo.reserve((size_t)n_rows * 4 + 64 * XCDS);
     for (int x = 0; x < XCDS; x++) {
-        sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.tile[x] = (int32_t)(rowinfo.size() / (4 * 4 * SPMM_RW));
+        sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.rows[x] = (int32_t)(rowinfo.size() / 4);
+        const size_t slice_begin = rowinfo.size();
         for (int64_t p = xs[x]; p < xs[x + 1]; p++) {
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
             const int32_t s0 = ip[(size_t)r], deg = ip[(size_t)r + 1] - s0;
@@ -957,11 +984,19 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
                 rowinfo.insert(rowinfo.end(), e, e + 4);
             }
         }
+        // rows of a pack run in lock step: sort every window of SHORT_WIN short rows by length (stable)
+        for (size_t w0 = slice_begin; w0 < rowinfo.size(); w0 += 4 * SHORT_WIN) {
+            const size_t w1 = std::min(rowinfo.size(), w0 + 4 * (size_t)SHORT_WIN), n = (w1 - w0) / 4;
+            std::vector<std::array<int32_t, 4>> tmp(n);
+            for (size_t i = 0; i < n; i++) for (int k = 0; k < 4; k++) tmp[i][k] = rowinfo[w0 + 4 * i + k];
+            std::stable_sort(tmp.begin(), tmp.end(), [](const std::array<int32_t, 4> &p, const std::array<int32_t, 4> &q) { return p[2] > q[2]; });
+            for (size_t i = 0; i < n; i++) for (int k = 0; k < 4; k++) rowinfo[w0 + 4 * i + k] = tmp[i][k];
+        }
         const int32_t pad[4] = {-1, 0, 0, 0};
         while ((chunks.size() / 4) % 4) chunks.insert(chunks.end(), pad, pad + 4);
-        while ((rowinfo.size() / 4) % (4 * SPMM_RW)) rowinfo.insert(rowinfo.end(), pad, pad + 4);
+        while ((rowinfo.size() / 4) % SLICE_PAD) rowinfo.insert(rowinfo.end(), pad, pad + 4);
     }
-    sp.cblk[XCDS] = (int32_t)(chunks.size() / 16); sp.tile[XCDS] = (int32_t)(rowinfo.size() / (4 * 4 * SPMM_RW));
+    sp.cblk[XCDS] = (int32_t)(chunks.size() / 16); sp.rows[XCDS] = (int32_t)(rowinfo.size() / 4);
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
     g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr;
