@@ -147,6 +147,11 @@ class _EvalIndex:
         self.test_len = lens
         self.test_ptr = torch.from_numpy(ptr).to(dev)
         self.test_idx = torch.from_numpy(items).to(dev)
+        # what the fused kernels take: int32 ids, the test lists ascending per user
+        self.users32 = torch.from_numpy(self.users.astype(np.int32)).to(dev)
+        self.train_idx32 = self.train_idx.to(torch.int32)
+        order = np.lexsort((items, np.repeat(np.arange(len(self.users)), lens)))
+        self.test_sorted32 = torch.from_numpy(items[order].astype(np.int32)).to(dev)
 
     @staticmethod
     def _expand(ptr, rows):
@@ -156,6 +161,27 @@ class _EvalIndex:
         local = torch.repeat_interleave(torch.arange(len(rows), device=ptr.device), lens)
         offs = torch.arange(int(lens.sum()), device=ptr.device) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
         return local, torch.repeat_interleave(start, lens) + offs
+
+
+def _test_fused(Recmodel, ev, max_K):
+    """Procedure.py:162-192 in two launches: lgcn_eval_topk (scores on the matrix cores + train mask +
+    top-K, no score matrix in memory) and lgcn_eval_metrics (hits, precision / recall / NDCG, sums)."""
+    lib = _lib.load()
+    E = Recmodel.propagated_table()
+    n = len(ev.users)
+    dev = E.device
+    topk = torch.empty(n, max_K, dtype=torch.int32, device=dev)
+    _lib.check(lib.lgcn_eval_topk(_lib.tp(E), Recmodel.n_users, Recmodel.m_items, Recmodel.latent_dim,
+                                  _lib.tp(ev.users32), n, _lib.tp(ev.train_ptr), _lib.tp(ev.train_idx32),
+                                  max_K, _lib.tp(topk), None, _lib.current_stream()), "lgcn_eval_topk")
+    ks = torch.tensor(list(world.topks), dtype=torch.int32)
+    per_user = torch.empty(n, 3 * len(ks), dtype=torch.float64, device=dev)
+    sums = torch.empty(3 * len(ks), dtype=torch.float64, device=dev)
+    _lib.check(lib.lgcn_eval_metrics(_lib.tp(topk), n, max_K, _lib.tp(ev.test_ptr), _lib.tp(ev.test_sorted32),
+                                     _lib.tp(ks), len(ks), _lib.tp(per_user), _lib.tp(sums), _lib.current_stream()),
+               "lgcn_eval_metrics")
+    m = (sums.cpu().numpy() / max(n, 1)).reshape(3, len(ks))
+    return {'precision': m[0], 'recall': m[1], 'ndcg': m[2]}, topk
 
 
 def Test(dataset, Recmodel, epoch, w=None, multicore=0):
@@ -175,6 +201,11 @@ def Test(dataset, Recmodel, epoch, w=None, multicore=0):
             dataset._lgcn_eval_index = ev
         except Exception:
             pass
+    fused = max_K <= 32 and int(world.config.get('eval_fused', 1)) and hasattr(Recmodel, 'propagated_table')
+    if fused:
+        with torch.no_grad():
+            results, _ = _test_fused(Recmodel, ev, max_K)
+        return _finish_test(results, epoch, w)
     per_user = {m: [] for m in ('precision', 'recall', 'ndcg')}
     chunk = max(u_batch_size, min(8192, (1 << 28) // max(1, dataset.m_items)) // u_batch_size * u_batch_size)
     with torch.no_grad():
@@ -194,7 +225,11 @@ def Test(dataset, Recmodel, epoch, w=None, multicore=0):
             for m in per_user:
                 per_user[m].append(bm[m])
     results = {m: np.mean(np.concatenate(per_user[m], 0), axis=0) for m in per_user}
+    return _finish_test(results, epoch, w)
 
+
+def _finish_test(results, epoch, w):
+    """CSV / tensorboard side effects and the return value of Procedure.py:195-206."""
     save_path = world.config.get('path', world.config.get('checkpoint_dir', './checkpoints'))
     os.makedirs(save_path, exist_ok=True)
     valid_csv = os.path.join(save_path, 'valid_epoch_metrics.csv')

@@ -63,6 +63,8 @@ SIGNATURES = {
     "lgcn_train_step_dp_dense_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
+    "lgcn_eval_topk": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_eval_metrics": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),
     "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),

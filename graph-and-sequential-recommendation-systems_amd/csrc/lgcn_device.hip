@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <algorithm>
@@ -396,6 +397,26 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #ifndef SPMM_U
 #define SPMM_U 8              /* gathers in flight per lane in the short-row path */
 #endif
+// One batch of U gathers of a lane group walking ITS OWN row: entries u0 .. u0+U-1 of the group's staged
+// row (past the row's end: zero-weight re-read of its last entry -- unconditional loads, see gather_batch).
+template <int D, typename TI, bool SPARSE, int U>
+__device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycnt, int last, const GatherSrc &src, int l,
+                                           typename Geo<D, TI, SPARSE>::Acc &acc) {
+    typedef Raw<TI, SPARSE> R;
+    int2 cv[U]; typename R::T xr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = u0 + u;
+        cv[u] = mystage[min(e, last)];
+        if (e >= mycnt) cv[u].y = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) xr[u] = R::load(src, cv[u].x, D, l);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u], src.div);
+}
+
 // rows per workgroup of a kernel variant: 4 waves x PACKS packs x NPW rows
 template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= 4 ? 1 : 4 / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
 
@@ -524,20 +545,13 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         const int2 *mystage = stage + g * ST;
         const int last = max(mycnt - 1, 0);
         Acc acc = zerov<C>();
-        for (int u0 = 0; u0 < maxcnt; u0 += U) {
-            int2 cv[U]; typename R::T xr[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int e = u0 + u;
-                cv[u] = mystage[min(e, last)];
-                if (e >= mycnt) cv[u].y = 0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) xr[u] = R::load(src, cv[u].x, D, l);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u], src.div);
-        }
+        // batch depth follows the pack's longest row (8 / 4 / 2 / 1 gathers per lane): a padded gather costs
+        // the address path as much as a useful one
+        int u0 = 0;
+        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) pack_batch<D, TI, SP, (U >= 8 ? 8 : U)>(mystage, u0, mycnt, last, src, l, acc);
+        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) pack_batch<D, TI, SP, (U >= 4 ? 4 : U)>(mystage, u0, mycnt, last, src, l, acc);
+        for (; maxcnt - u0 > 1; u0 += 2) pack_batch<D, TI, SP, 2>(mystage, u0, mycnt, last, src, l, acc);
+        if (maxcnt - u0 > 0) pack_batch<D, TI, SP, 1>(mystage, u0, mycnt, last, src, l, acc);
         const int mrow = __shfl(my_row, g);
         if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
@@ -825,7 +839,8 @@ static void launch_spmm_t(SpmmArgs a, int64_t bm_words, hipStream_t st) {
     if (grid == 0) return;
     size_t dyn = 0;
     a.bm_words = 0;
-    if ((MODE & M_SPARSE) && bm_words > 0 && bm_words <= BM_LDS_MAX_WORDS) { a.bm_words = (int32_t)bm_words; dyn = 4 * (size_t)bm_words; }
+    static const bool bm_lds = getenv("LGCN_BM_LDS") && atoi(getenv("LGCN_BM_LDS")) != 0;     // experiment switch
+    if ((MODE & M_SPARSE) && bm_lds && bm_words > 0 && bm_words <= BM_LDS_MAX_WORDS) { a.bm_words = (int32_t)bm_words; dyn = 4 * (size_t)bm_words; }
     hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), dyn, st, a);
 }
 

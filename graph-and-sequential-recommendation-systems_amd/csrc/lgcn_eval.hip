@@ -1,0 +1,260 @@
+// lgcn_eval.hip -- fused full-ranking evaluation for gfx950.
+//
+// Replaces, for one launch over all test users (reference: LightGCN_work/code):
+//   model.py:114-123      getUsersRating: rating = U_b . I^T  (the reference re-propagates per 100 users;
+//                         here the propagated table comes in once from lgcn_propagate_mean)
+//   Procedure.py:177-181  rating[train positives] = -(1<<10)
+//   Procedure.py:183      torch.topk(rating, k=max(topks))
+//   Procedure.py:89-121 + utils.py:173-217   per-user hits, precision / recall / NDCG, summed over users
+// without ever materialising the [users, m_items] score matrix.
+//
+// k_eval_topk: the one dense contraction of the system -> matrix cores.  fp32 in / fp32 accumulate
+// (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD) so the ranking is the reference's fp32 ranking.
+//   * workgroup = 4 waves x 32 users; the users' rows are the B operand and stay in registers for the
+//     whole item sweep (D/2 VGPRs per lane: lane (j, h) holds elements [h*D/2, (h+1)*D/2) of user j --
+//     the k order inside a dot product is free, so each half-row is one contiguous run);
+//   * items stream through LDS in tiles of 32 rows (coalesced 16-byte global loads, double buffered,
+//     rows padded by 16 B so the ds_read_b128 of 32 lanes at the same column hit different banks);
+//     every wave multiplies the same item tile with its own users: D/2 MFMAs per 32 x 32 scores;
+//   * the accumulator layout puts a user on a lane (col = lane & 31) and 16 of the tile's items in its
+//     registers, so the train-positive mask is a 32-bit word per user (built one tile ahead from the
+//     sorted train CSR by a cursor whose next entry is always already loaded) and the running top-K
+//     is per lane: a threshold compare per score, and only a score above the lane's current K-th best
+//     touches its K-entry list in LDS (replace the minimum, rescan for the new minimum).  The lists
+//     of the two lanes of a user are merged and sorted once at the end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "lgcn_hip.h"
+#include "lgcn_internal.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define EVAL_KMAX 32
+#define EVAL_NEG_INF (-3.0e38f)
+
+struct EvalArgs {
+    const float *E; int32_t n_users, m_items;
+    const int32_t *users; int32_t n_eval;
+    const int64_t *train_ptr; const int32_t *train_idx;
+    int32_t K;
+    int32_t *out_items; float *out_scores;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
+    constexpr int HALF = D / 2, RS = D + 4;            // row stride of the LDS item tile (floats)
+    constexpr int LPT = 32 * D * 4 / 16 / 256;          // 16-byte pieces per thread per item tile
+    static_assert(LPT >= 1, "tile smaller than the workgroup");
+    __shared__ __attribute__((aligned(16))) float tile_lds[2][32 * RS];
+    __shared__ float list_s[256][EVAL_KMAX + 1];       // +1: odd stride, lanes scan their lists conflict-free
+    __shared__ int32_t list_i[256][EVAL_KMAX + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int K = a.K;
+    const float *items = a.E + (int64_t)a.n_users * D;
+
+    // ---- this lane's user: half a row in registers (B operand)
+    const int64_t slot = (int64_t)blockIdx.x * 128 + wid * 32 + j;
+    const bool have = slot < a.n_eval;
+    const int32_t uid = have ? a.users[slot] : 0;
+    float b[HALF];
+    {
+        const float *up = a.E + (int64_t)uid * D + h * HALF;
+#pragma unroll
+        for (int s = 0; s < HALF; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(up + s);
+            b[s] = v.x; b[s + 1] = v.y; b[s + 2] = v.z; b[s + 3] = v.w;
+        }
+    }
+    // ---- train-positive cursor (lower lane of the pair walks it; the mask is shared with the upper one)
+    int64_t tp = 0, tend = 0;
+    int32_t nid = 0x7fffffff, nnid = 0x7fffffff;
+    if (have && h == 0) {
+        tp = a.train_ptr[uid]; tend = a.train_ptr[uid + 1];
+        if (tp < tend) nid = a.train_idx[tp];
+        if (tp + 1 < tend) nnid = a.train_idx[tp + 1];
+    }
+    for (int k = 0; k < K; k++) { list_s[tid][k] = EVAL_NEG_INF; list_i[tid][k] = -1; }
+    float thr = EVAL_NEG_INF;      // the lane's K-th best so far
+    int pmin = 0;                  // where it sits in the list
+
+    const int ntiles = (a.m_items + 31) / 32;
+    // piece p of a tile: item row p / (D/4), 16-byte column p % (D/4)
+    f32x4 pre[LPT];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const int p = tid + q * 256, r = p / (D / 4), c = p % (D / 4);
+            const int64_t item = (int64_t)t * 32 + r;
+            pre[q] = item < a.m_items ? *reinterpret_cast<const f32x4 *>(items + item * D + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const int p = tid + q * 256, r = p / (D / 4), c = p % (D / 4);
+            *reinterpret_cast<f32x4 *>(&tile_lds[buf][r * RS + c * 4]) = pre[q];
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t + 1);                  // in flight under this tile's MFMAs
+        // ---- mask of this tile's train positives for my user
+        const int base = t * 32;
+        uint32_t mask = 0;
+        while (nid < base + 32) {                               // nid >= base always: tiles ascend
+            mask |= 1u << (nid - base);
+            nid = nnid; tp++;
+            nnid = (tp + 1 < tend) ? a.train_idx[tp + 1] : 0x7fffffff;
+        }
+        mask = __shfl(mask, j);                                 // lane j (h = 0) holds the user's mask
+        // ---- 32 items x 32 users: scores[item i][user j] = sum_k I[i][k] U[j][k]
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float *arow = &tile_lds[buf][j * RS + h * HALF];  // A operand: lane (i = j, h) holds item i's half row
+#pragma unroll
+        for (int s = 0; s < HALF; s += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[s + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[s + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[s + 3], acc, 0, 0, 0);
+        }
+        // ---- my 16 scores: item row = (reg & 3) + 8 * (reg >> 2) + 4 * h
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float sc = acc[reg];
+            if ((mask >> row) & 1u) sc = -1024.0f;                      // Procedure.py:181
+            if (base + row >= a.m_items) sc = EVAL_NEG_INF;             // past the table
+            if (sc > thr) {
+                list_s[tid][pmin] = sc; list_i[tid][pmin] = base + row;
+                float m = list_s[tid][0]; int pm = 0;
+                for (int k = 1; k < K; k++) { const float v = list_s[tid][k]; if (v < m) { m = v; pm = k; } }
+                thr = m; pmin = pm;
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- merge the two lanes of a user, sort descending (ties: lower item id first)
+    __syncthreads();
+    if (h == 0 && have) {
+        const int other = tid + 32;
+        for (int r = 0; r < K; r++) {
+            float best = EVAL_NEG_INF * 2.0f; int bi = 0x7fffffff, bw = -1, bk = 0;
+            for (int w = 0; w < 2; w++) {
+                const int src = w ? other : tid;
+                for (int k = 0; k < K; k++) {
+                    const float v = list_s[src][k]; const int id = list_i[src][k];
+                    if (id >= 0 && (v > best || (v == best && id < bi))) { best = v; bi = id; bw = src; bk = k; }
+                }
+            }
+            if (bw >= 0) list_i[bw][bk] = -1;                  // taken
+            a.out_items[slot * K + r] = bw >= 0 ? bi : -1;
+            if (a.out_scores) a.out_scores[slot * K + r] = best;
+        }
+    }
+}
+
+// per-user metrics from the ranked ids: r_j = [id_j in the user's test list] (sorted: binary search)
+struct MetricArgs {
+    const int32_t *topk; int32_t n_eval, K;
+    const int64_t *test_ptr; const int32_t *test_idx;      // per evaluated slot, ids ascending
+    int32_t ks[8]; int32_t n_ks;
+    double *per_user;                                        // [n_eval, 3 * n_ks]: precision | recall | ndcg
+};
+
+__global__ void __launch_bounds__(256) k_eval_metrics(MetricArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_eval) return;
+    const int64_t b = a.test_ptr[s], e = a.test_ptr[s + 1];
+    const int len = (int)(e - b);
+    uint64_t hits = 0;
+    for (int r = 0; r < a.K; r++) {
+        const int32_t id = a.topk[s * a.K + r];
+        int64_t lo = b, hi = e;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.test_idx[mid] < id) lo = mid + 1; else hi = mid; }
+        if (lo < e && a.test_idx[lo] == id) hits |= 1ull << r;
+    }
+    for (int q = 0; q < a.n_ks; q++) {
+        const int k = a.ks[q];
+        double right = 0.0, dcg = 0.0, idcg = 0.0;
+        for (int r = 0; r < k; r++) {
+            const double disc = 1.0 / log2((double)(r + 2));
+            if ((hits >> r) & 1ull) { right += 1.0; dcg += disc; }
+            if (r < len) idcg += disc;
+        }
+        if (idcg == 0.0) idcg = 1.0;
+        double *o = a.per_user + s * 3 * a.n_ks;
+        o[q] = right / (double)k;                         // utils.py:173-187
+        o[a.n_ks + q] = len > 0 ? right / (double)len : 0.0;
+        o[2 * a.n_ks + q] = dcg / idcg;                   // utils.py:190-203
+    }
+}
+
+// sums over users in a fixed order (one workgroup: deterministic)
+__global__ void __launch_bounds__(256) k_eval_sum(const double *per_user, int32_t n_eval, int32_t width, double *sums) {
+    __shared__ double part[256];
+    for (int c = 0; c < width; c++) {
+        double acc = 0.0;
+        for (int64_t s = threadIdx.x; s < n_eval; s += 256) acc += per_user[s * width + c];
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[c] = part[0];
+        __syncthreads();
+    }
+}
+
+extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
+                              const int32_t *users, int32_t n_eval,
+                              const int64_t *train_indptr, const int32_t *train_indices,
+                              int32_t K, int32_t *topk_items, float *topk_scores, void *stream) {
+    if (!E || !users || !train_indptr || !train_indices || !topk_items || n_users <= 0 || m_items <= 0 || n_eval < 0) {
+        lgcn_set_error("lgcn_eval_topk: invalid argument"); return 3;
+    }
+    if (K < 1 || K > EVAL_KMAX || K > m_items) { lgcn_set_error("lgcn_eval_topk: K must be in 1..32 and <= m_items"); return 3; }
+    if (n_eval == 0) return 0;
+    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores};
+    const unsigned grid = (unsigned)((n_eval + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+    case 32: hipLaunchKernelGGL((k_eval_topk<32>), dim3(grid), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((k_eval_topk<64>), dim3(grid), dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((k_eval_topk<128>), dim3(grid), dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((k_eval_topk<256>), dim3(grid), dim3(256), 0, st, a); break;
+    default: lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
+    }
+    if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_topk: launch failed"); return 10; }
+    return 0;
+}
+
+extern "C" int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,
+                                 const int64_t *test_indptr, const int32_t *test_items_sorted,
+                                 const int32_t *ks, int32_t n_ks, double *per_user, double *sums, void *stream) {
+    if (!topk_items || !test_indptr || !test_items_sorted || !ks || !per_user || !sums || n_eval < 0) {
+        lgcn_set_error("lgcn_eval_metrics: invalid argument"); return 3;
+    }
+    if (n_ks < 1 || n_ks > 8 || K < 1 || K > 64) { lgcn_set_error("lgcn_eval_metrics: 1..8 cut-offs, K <= 64"); return 3; }
+    MetricArgs a{};
+    a.topk = topk_items; a.n_eval = n_eval; a.K = K; a.test_ptr = test_indptr; a.test_idx = test_items_sorted;
+    a.n_ks = n_ks; a.per_user = per_user;
+    for (int q = 0; q < n_ks; q++) {
+        if (ks[q] < 1 || ks[q] > K) { lgcn_set_error("lgcn_eval_metrics: a cut-off exceeds K"); return 3; }
+        a.ks[q] = ks[q];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (n_eval > 0) hipLaunchKernelGGL(k_eval_metrics, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_eval_sum, dim3(1), dim3(256), 0, st, per_user, n_eval, 3 * n_ks, sums);
+    if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_metrics: launch failed"); return 10; }
+    return 0;
+}

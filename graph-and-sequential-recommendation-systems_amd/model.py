@@ -241,12 +241,18 @@ class LightGCN(nn.Module):
         self._cache = None
         return super().train(mode)
 
+    def propagated_table(self):
+        """The [N,d] fp32 table computer() splits into users / items, memoised between
+        invalidate_cache() / train() calls (what the fused evaluation kernels read)."""
+        if self._cache is None:
+            with torch.no_grad():
+                self._cache = self._propagate_dense()
+        return self._cache
+
     def computer(self):
         """model.py:201-231 -> (all_users [n_users,d], all_items [m_items,d])."""
         if not self.training and not torch.is_grad_enabled():
-            if self._cache is None:            # eval: propagate once instead of once per user batch
-                self._cache = self._propagate_dense()
-            out = self._cache
+            out = self.propagated_table()       # eval: propagate once instead of once per user batch
         elif torch.is_grad_enabled() and (self.embedding_user.weight.requires_grad
                                           or self.embedding_item.weight.requires_grad):
             out = _Propagate.apply(self.embedding_user.weight, self.embedding_item.weight, self)

@@ -66,6 +66,9 @@ def build_parser():
                    help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
     p.add_argument('--prefetch_epoch', type=int, default=0,
                    help='NEW: 1 = sample/shuffle/upload epoch e+1 while epoch e runs on the GPU')
+    p.add_argument('--eval_fused', type=int, default=1,
+                   help='NEW: 1 = Procedure.Test through the fused HIP kernels (MFMA scores + mask + top-k, metrics on device); '
+                        '0 = torch matmul/topk harness')
     p.add_argument('--data_path', type=str, default=None,
                    help='NEW: directory that holds <dataset>/train.txt (default: <root>/data)')
     return p

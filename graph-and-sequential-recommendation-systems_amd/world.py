@@ -99,6 +99,7 @@ def configure(argv=None):
     config['xcd_remap'] = args.xcd_remap
     config['row_order'] = args.row_order
     config['prefetch_epoch'] = args.prefetch_epoch
+    config['eval_fused'] = args.eval_fused
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

@@ -204,6 +204,28 @@ int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t 
                              const float *gathered, float *loss_out, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Device: fused full-ranking evaluation -- replaces the body of Procedure.Test  */
+/* ------------------------------------------------------------------------ */
+/* For every listed user: scores against ALL items (model.getUsersRating, model.py:114-123:
+ * U_b . I^T on the propagated table E[N,d] -- fp32 matrix cores, fp32 accumulate), train positives
+ * set to -(1<<10) (Procedure.py:177-181; CSR with int64 indptr[n_users+1] and ascending int32
+ * indices = dataset.allPos), top-K (Procedure.py:183) -- in one kernel, the [users, m_items]
+ * score matrix is never materialised.  topk_items [n_eval,K] int32, best first (ties: lower
+ * item id first); topk_scores [n_eval,K] or NULL.  1 <= K <= 32.                          */
+int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
+                   const int32_t *users, int32_t n_eval,
+                   const int64_t *train_indptr, const int32_t *train_indices,
+                   int32_t K, int32_t *topk_items, float *topk_scores, void *stream);
+/* Per-user precision / recall / NDCG at the cut-offs ks[n_ks] (Procedure.test_one_batch,
+ * Procedure.py:89-121; utils.RecallPrecision_ATk / NDCGatK_r / getLabel, utils.py:173-217) from the
+ * ranked ids and the users' test lists (CSR over the n_eval slots, ids ASCENDING per slot), in
+ * float64; per_user [n_eval, 3*n_ks] = precision | recall | ndcg, sums [3*n_ks] = their sums over
+ * the users in a fixed order (the reference averages them, Procedure.py:191-192).        */
+int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,
+                      const int64_t *test_indptr, const int32_t *test_items_sorted,
+                      const int32_t *ks, int32_t n_ks, double *per_user, double *sums, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Data parallel over RCCL (no counterpart in the reference: SURVEY 2, north_star) */
 /* ------------------------------------------------------------------------ */
 /* RCCL is resolved at run time (dlopen of the librccl already mapped into the process, else

@@ -5,8 +5,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = [os.path.join(REPO, "graph-and-sequential-recommendation-systems_amd/csrc", f) for f in os.listdir(os.path.join(REPO, "graph-and-sequential-recommendation-systems_amd/csrc")) if f.endswith(".hip")]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 extra = sys.argv[2:]
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-c", "--cuda-device-only",
-                      "-Rpass-analysis=kernel-resource-usage", *extra, *src, "-o", "/dev/null"], capture_output=True, text=True).stderr
+out = ""
+for f in src:
+    out += subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-c", "--cuda-device-only",
+                           "-Rpass-analysis=kernel-resource-usage", *extra, f, "-o", "/dev/null"], capture_output=True, text=True).stderr
 cur = {}
 for line in out.splitlines():
     if "error" in line: print(line)
