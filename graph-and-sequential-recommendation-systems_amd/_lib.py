@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -47,7 +47,7 @@ SIGNATURES = {
     "lgcn_build_user_item_csr": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgcn_adj_rowsum": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "lgcn_build_norm_adj": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.POINTER(_vp)]),
+    "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(_vp)]),
     "lgcn_graph_destroy": (None, [_vp]),
     "lgcn_spmm_csr": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "lgcn_propagate_mean": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -71,7 +71,9 @@ SIGNATURES = {
     "lgcn_dp_destroy": (None, [_vp]),
     "lgcn_dp_world": (C.c_int, [_vp]),
     "lgcn_dp_rank": (C.c_int, [_vp]),
-    "lgcn_train_epoch_dp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_train_epoch_dp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "lgcn_rs_phase": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_rs_buffer": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int32)]),
 }
 
 _LIB = None
@@ -178,8 +180,9 @@ class Graph:
                 raise LgcnError("Graph: xcd_start must hold 9 positions")
         h = _vp()
         check(load().lgcn_graph_create(tp(self.indptr), tp(self.indices), tp(self.vals), self.n_rows, nnz,
-                                       int(d_max), tp(self.row_order), npp(xs) if xs is not None else None,
-                                       C.byref(h)), "lgcn_graph_create")
+                                       int(d_max), tp(self.row_order),
+                                       int(self.row_order.numel()) if self.row_order is not None else self.n_rows,
+                                       npp(xs) if xs is not None else None, C.byref(h)), "lgcn_graph_create")
         self.handle = h
 
     def spmm(self, x, y_dtype=None):

@@ -788,30 +788,9 @@ __global__ void __launch_bounds__(256) k_finish(SlotArgs a) {
             if (l == 0) a.bitmap[row >> 5] = 0u;
         }
     }
-    if (blockIdx.x == 0) {   // deterministic loss reduction: fixed strided partials + LDS tree
-        __shared__ float sl[256], sr[256];
-        float fl = 0.f, fr = 0.f;
-        if (a.gathered) {
-            const int64_t blk = (int64_t)3 * a.shard * D + 2 * a.shard;
-            for (int b = threadIdx.x; b < a.B; b += 256) {
-                const float *t = a.gathered + (b / a.shard) * blk + (int64_t)3 * a.shard * D;
-                fl += t[b % a.shard]; fr += t[a.shard + b % a.shard];
-            }
-        } else {
-            for (int b = threadIdx.x; b < a.B; b += 256) { fl += a.terms[b]; fr += a.terms[a.B + b]; }
-        }
-        sl[threadIdx.x] = fl; sr[threadIdx.x] = fr;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) { sl[threadIdx.x] += sl[threadIdx.x + w]; sr[threadIdx.x] += sr[threadIdx.x + w]; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const float bpr = -(sl[0] / (float)a.B);
-            const float reg = (0.5f * sr[0]) / (float)a.B;
-            a.loss_out[0] = bpr + a.decay * reg; a.loss_out[1] = bpr; a.loss_out[2] = reg;
-        }
-    }
+    // the same single-wave, fixed-order reduction as the fused finish of the last SpMM: identical bits
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, (int)threadIdx.x);
 }
 
 __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, const int64_t *perm, int64_t T,
@@ -923,7 +902,7 @@ __global__ void __launch_bounds__(256) k_index_range(const int32_t *indices, int
 
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                                  int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                                 const int64_t *xcd_start, lgcn_graph **out) {
+                                 int64_t n_order, const int64_t *xcd_start, lgcn_graph **out) {
     if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
         n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
     if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
@@ -945,13 +924,15 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         if (hbad) { lgcn_set_error("lgcn_graph_create: column index out of range [0, n_rows)"); return 3; }
     }
     std::vector<int32_t> ord;
-    if (row_order) {             // must be a permutation of 0..n_rows-1
-        ord.resize((size_t)n_rows);
-        HIP_OK(hipMemcpy(ord.data(), row_order, sizeof(int32_t) * ord.size(), hipMemcpyDeviceToHost));
+    if (!row_order) n_order = n_rows;
+    if (n_order < 0 || n_order > n_rows) { lgcn_set_error("lgcn_graph_create: n_order out of range"); return 3; }
+    if (row_order) {             // a permutation of 0..n_rows-1, or a subset of the rows without repetition
+        ord.resize((size_t)n_order);
+        if (n_order) HIP_OK(hipMemcpy(ord.data(), row_order, sizeof(int32_t) * ord.size(), hipMemcpyDeviceToHost));
         std::vector<char> seen((size_t)n_rows, 0);
-        for (int64_t i = 0; i < n_rows; i++) {
+        for (int64_t i = 0; i < n_order; i++) {
             const int32_t r = ord[(size_t)i];
-            if (r < 0 || r >= n_rows || seen[(size_t)r]) { lgcn_set_error("lgcn_graph_create: row_order is not a permutation"); return 3; }
+            if (r < 0 || r >= n_rows || seen[(size_t)r]) { lgcn_set_error("lgcn_graph_create: row_order is not a permutation / repeats a row"); return 3; }
             seen[(size_t)r] = 1;
         }
     }
@@ -961,25 +942,29 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     int64_t xs[XCDS + 1];
     if (xcd_start) {
         for (int x = 0; x <= XCDS; x++) xs[x] = xcd_start[x];
-        bool ok = xs[0] == 0 && xs[XCDS] == n_rows;
+        bool ok = xs[0] == 0 && xs[XCDS] == n_order;
         for (int x = 0; x < XCDS; x++) ok = ok && xs[x] <= xs[x + 1];
-        if (!ok) { lgcn_set_error("lgcn_graph_create: xcd_start must be 9 non-decreasing positions from 0 to n_rows"); return 3; }
+        if (!ok) { lgcn_set_error("lgcn_graph_create: xcd_start must be 9 non-decreasing positions from 0 to n_order"); return 3; }
     } else {                     // balance the work: non-zeros plus a per-row constant
-        const double total = (double)nnz + 4.0 * (double)n_rows;
+        double total = 4.0 * (double)n_order;
+        for (int64_t p = 0; p < n_order; p++) {
+            const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
+            total += (double)(ip[(size_t)r + 1] - ip[(size_t)r]);
+        }
         double acc = 0.0; int x = 1;
         xs[0] = 0;
-        for (int64_t p = 0; p < n_rows && x < XCDS; p++) {
+        for (int64_t p = 0; p < n_order && x < XCDS; p++) {
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
             acc += (double)(ip[(size_t)r + 1] - ip[(size_t)r]) + 4.0;
             while (x < XCDS && acc >= total * x / XCDS) xs[x++] = p + 1;
         }
-        while (x <= XCDS) xs[x++] = n_rows;
-        xs[XCDS] = n_rows;
+        while (x <= XCDS) xs[x++] = n_order;
+        xs[XCDS] = n_order;
     }
     // ---- per slice: chunks of its long rows (padded to whole workgroups), then its short rows
     std::vector<int32_t> long_row, long_nch, chunks, rowinfo;
     SlicePlan sp{};
-    rowinfo.reserve((size_t)n_rows * 4 + 64 * XCDS);
+    rowinfo.reserve((size_t)n_order * 4 + 4 * SLICE_PAD * XCDS);
     for (int x = 0; x < XCDS; x++) {
         sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.rows[x] = (int32_t)(rowinfo.size() / 4);
         const size_t slice_begin = rowinfo.size();
@@ -1208,49 +1193,67 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     return 0;
 }
 
+static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
+                          const float *gathered, int32_t shard, int32_t world, float *loss_out) {
+    const lgcn_train_config &c = x->c;
+    SlotArgs s{};
+    s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
+    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
+    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
+    return s;
+}
+static unsigned slot_grid(const lgcn_ctx *x, int32_t B) {
+    const int spb = 256 / (x->c.d / 4);
+    return (unsigned)((3 * (int64_t)B + spb - 1) / spb);
+}
+
+// buffer the backward layer k writes (k > 1): ping-pong inside the activation workspace (forward
+// activations are dead by then)
+static void *bwd_buffer(const lgcn_ctx *x, int k) {
+    return (x->c.K == 2) ? x->act[1] : x->act[1 + ((x->c.K - k) & 1)];
+}
+
+// One layer of the Horner chain h_{k-1} = Gs + A h_k (k = K: sparse input Gs; k = 1: feeds Adam).
+// fused_finish: the Adam launch also zeroes the G64 rows it consumes and reduces the loss (single-GPU
+// and batch-sharded steps, where every rank runs every row); the row-sharded step finishes separately.
+static int backward_layer(lgcn_ctx *x, int k, int32_t B, const float *gathered, int32_t shard, float *loss_out,
+                          bool fused_finish, hipStream_t st) {
+    const lgcn_train_config &c = x->c;
+    const bool first = (k == c.K), last = (k == 1);
+    SpmmArgs a = base_spmm(x);
+    a.X = first ? nullptr : bwd_buffer(x, k + 1);
+    if (!last) a.Y = bwd_buffer(x, k);
+    else {
+        const double bc1 = 1.0 - pow(c.beta1, (double)x->step);
+        const double bc2 = 1.0 - pow(c.beta2, (double)x->step);
+        a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
+        a.step_size = (float)(c.lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
+        a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
+        if (!first && fused_finish) {       // K >= 2: this launch also cleans the workspace and reduces the loss
+            a.clear = 1; a.terms = c.terms; a.gathered = gathered; a.loss_out = loss_out;
+            a.B = B; a.shard = shard; a.decay = c.decay;
+        }
+    }
+    const int prev_dt = first ? LGCN_F32 : c.act_dtype;
+    if (first && last) return launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st, x->bm_words);
+    if (first) return launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st, x->bm_words);
+    if (last) return launch_spmm<M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
+    return launch_spmm<M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
+}
+
 // [DP scatter] + backward chain + Adam + finish
 static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
                         const float *gathered, int32_t shard, int32_t world, float *loss_out, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
-    SlotArgs s{};
-    s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
-    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
-    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
-    const int spb = 256 / (c.d / 4);
-    const unsigned sgrid = (unsigned)((3 * (int64_t)B + spb - 1) / spb);
+    SlotArgs s = slot_args(x, users, pos, neg, B, gathered, shard, world, loss_out);
+    const unsigned sgrid = slot_grid(x, B);
     if (gathered) { DISPATCH_D(c.d, hipLaunchKernelGGL((k_scatter<D>), dim3(sgrid), dim3(256), 0, st, s)); }
-
     x->step += 1;
-    const double bc1 = 1.0 - pow(c.beta1, (double)x->step);
-    const double bc2 = 1.0 - pow(c.beta2, (double)x->step);
     // Horner: h_{K-1} = Gs + A Gs (sparse input); h_{k-1} = Gs + A h_k; last one feeds Adam
-    const void *prev = nullptr; int prev_dt = LGCN_F32;
     for (int k = c.K; k >= 1; k--) {
-        SpmmArgs a = base_spmm(x);
-        a.X = prev;
-        const bool first = (k == c.K), last = (k == 1);
-        void *y = nullptr;
-        if (!last) {
-            // ping-pong inside the activation workspace (forward activations are dead now)
-            y = (c.K == 2) ? x->act[1] : x->act[1 + ((c.K - k) & 1)];
-            a.Y = y;
-        } else {
-            a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
-            a.step_size = (float)(c.lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
-            a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
-            if (!first) {       // K >= 2: this launch also cleans the workspace and reduces the loss
-                a.clear = 1; a.terms = c.terms; a.gathered = gathered; a.loss_out = loss_out;
-                a.B = B; a.shard = shard; a.decay = c.decay;
-            }
-        }
-        int rc;
-        if (first && last) rc = launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st, x->bm_words);
-        else if (first) rc = launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st, x->bm_words);
-        else if (last) rc = launch_spmm<M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
-        else rc = launch_spmm<M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
+        int rc = backward_layer(x, k, B, gathered, shard, loss_out, true, st);
         if (rc) return rc;
-        prev = y; prev_dt = c.act_dtype;
     }
     if (c.K >= 2) { x->flip ^= 1; return 0; }       // next step flags rows in the other bitmap
     DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(sgrid), dim3(256), 0, st, s));
@@ -1341,14 +1344,98 @@ extern "C" int lgcn_train_step_dp_part2(lgcn_ctx *x, const int32_t *users, const
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// Row-sharded propagation (SURVEY 8e "beyond the contract"; the analogue of the reference's A_split
+// row folds, dataloader.py:192-201): the context's graph plan holds only the rows this rank owns; a
+// phase computes those rows of one layer, and the owners' rows are exchanged before the next phase.
+// ---------------------------------------------------------------------------------
+extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                             int32_t B_global, int32_t world, int32_t rank, const float *gathered, float *loss_out, void *stream) {
+    int rc = check_batch(x, users, pos, neg, B_global);
+    if (rc) return rc;
+    const lgcn_train_config &c = x->c;
+    hipStream_t st = (hipStream_t)stream;
+    if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("lgcn_rs_phase: bad world/rank"); return 3; }
+    const int32_t shard = (B_global + world - 1) / world;
+    if ((rc = graph_acquire(c.graph, st))) return rc;
+    switch (phase) {
+    case LGCN_RS_FWD: {                               // X_k[owned] = (A X_{k-1})[owned], k = 1..K-1
+        if (k < 1 || k >= c.K) { lgcn_set_error("lgcn_rs_phase: forward layer out of range"); return 3; }
+        SpmmArgs a = base_spmm(x);
+        a.X = k == 1 ? (const void *)c.E0 : x->act[k - 1]; a.Y = x->act[k];
+        rc = launch_spmm<0>(a, c.d, k == 1 ? LGCN_F32 : c.act_dtype, c.act_dtype, st);
+        break;
+    }
+    case LGCN_RS_BPR: {                               // this rank's batch shard -> cfg.contrib
+        if (!c.contrib) { lgcn_set_error("lgcn_rs_phase: cfg.contrib exchange buffer missing"); return 3; }
+        const int32_t b_off = rank * shard;
+        int32_t B_local = B_global - b_off;
+        if (B_local > shard) B_local = shard;
+        if (B_local < 0) B_local = 0;
+        rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, false, st);
+        break;
+    }
+    case LGCN_RS_SCATTER: {                           // all ranks' gradient rows -> G64 + row flags
+        if (!gathered) { lgcn_set_error("lgcn_rs_phase: gathered blocks missing"); return 3; }
+        SlotArgs s = slot_args(x, users, pos, neg, B_global, gathered, shard, world, loss_out);
+        DISPATCH_D(c.d, hipLaunchKernelGGL((k_scatter<D>), dim3(slot_grid(x, B_global)), dim3(256), 0, st, s));
+        break;
+    }
+    case LGCN_RS_BWD:                                 // h_{k-1}[owned] = Gs + (A h_k)[owned], k = K..1; k = 1: Adam on the owned rows
+        if (k < 1 || k > c.K) { lgcn_set_error("lgcn_rs_phase: backward layer out of range"); return 3; }
+        if (k == c.K) x->step += 1;
+        rc = backward_layer(x, k, B_global, gathered, shard, loss_out, false, st);
+        break;
+    case LGCN_RS_FINISH: {                            // zero the batch rows of G64 + their flags, reduce the loss
+        if (!loss_out) { lgcn_set_error("lgcn_rs_phase: loss_out is null"); return 3; }
+        SlotArgs s = slot_args(x, users, pos, neg, B_global, gathered, shard, world, loss_out);
+        DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(slot_grid(x, B_global)), dim3(256), 0, st, s));
+        break;
+    }
+    default: lgcn_set_error("lgcn_rs_phase: unknown phase"); return 3;
+    }
+    if (rc) return rc;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// what a phase wrote and the owners must exchange: buffer + element type
+extern "C" int lgcn_rs_buffer(const lgcn_ctx *x, int32_t phase, int32_t k, void **buf, int32_t *dtype) {
+    if (!x || !buf || !dtype) { lgcn_set_error("lgcn_rs_buffer: null argument"); return 3; }
+    const lgcn_train_config &c = x->c;
+    if (phase == LGCN_RS_FWD && k >= 1 && k < c.K) { *buf = x->act[k]; *dtype = c.act_dtype; return 0; }
+    if (phase == LGCN_RS_BWD && k > 1 && k <= c.K) { *buf = bwd_buffer(x, k); *dtype = c.act_dtype; return 0; }
+    if (phase == LGCN_RS_BWD && k == 1) { *buf = c.E0; *dtype = LGCN_F32; return 0; }
+    lgcn_set_error("lgcn_rs_buffer: this phase exchanges nothing");
+    return 3;
+}
+
+// every owner broadcasts its two row ranges (users, items) of `buf` in place; one RCCL group
+static int rs_exchange(const RcclApi *api, lgcn_dp *dp, void *buf, int dtype, int d, const int64_t *ranges, hipStream_t st) {
+    const size_t es = dtype == LGCN_BF16 ? 2 : 4;
+    const ncclDataType_t nt = dtype == LGCN_BF16 ? ncclBfloat16 : ncclFloat32;
+    ncclResult_t r = api->GroupStart();
+    for (int q = 0; q < dp->world && r == ncclSuccess; q++)
+        for (int part = 0; part < 2 && r == ncclSuccess; part++) {
+            const int64_t lo = ranges[4 * q + 2 * part], hi = ranges[4 * q + 2 * part + 1];
+            if (hi <= lo) continue;
+            char *p = (char *)buf + (size_t)lo * d * es;
+            r = api->Broadcast(p, p, (size_t)(hi - lo) * d, nt, q, dp->comm, st);
+        }
+    if (r == ncclSuccess) r = api->GroupEnd(); else (void)api->GroupEnd();
+    if (r != ncclSuccess) { lgcn_set_error("RCCL broadcast of owned rows failed"); return 11; }
+    return 0;
+}
+
 // A whole data-parallel epoch from ONE host call: per global batch, part 1 -> RCCL collective on the
 // SAME stream (no host synchronisation, no Python between the kernels and the collective) -> part 2.
 extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, const int32_t *pos, const int32_t *neg,
-                                   int64_t T, int32_t B_global, int32_t reduce, float *gathered, float *loss_out,
-                                   void *stream) {
+                                   int64_t T, int32_t B_global, int32_t reduce, const int64_t *row_ranges, float *gathered,
+                                   float *loss_out, void *stream) {
     if (!x || !dp || !users || !pos || !neg || !loss_out) { lgcn_set_error("lgcn_train_epoch_dp: null argument"); return 3; }
-    if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE) { lgcn_set_error("lgcn_train_epoch_dp: reduce must be LGCN_DP_ROWS or LGCN_DP_DENSE"); return 3; }
-    if (reduce == LGCN_DP_ROWS && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
+    if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE && reduce != LGCN_DP_ROW_SHARDED) { lgcn_set_error("lgcn_train_epoch_dp: unknown reduce mode"); return 3; }
+    if (reduce == LGCN_DP_ROW_SHARDED && !row_ranges) { lgcn_set_error("lgcn_train_epoch_dp: row_ranges missing"); return 3; }
+    if (reduce != LGCN_DP_DENSE && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
     if (B_global <= 0 || B_global > x->c.max_batch) { lgcn_set_error("lgcn_train_epoch_dp: batch size out of range"); return 3; }
     const RcclApi *api = lgcn_rccl();
     if (!api) return 12;
@@ -1359,7 +1446,27 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
         const int32_t b = (int32_t)((T - t) < B_global ? (T - t) : B_global);
         int rc;
         ncclResult_t r;
-        if (reduce == LGCN_DP_ROWS) {
+        if (reduce == LGCN_DP_ROW_SHARDED) {
+            const int32_t K = x->c.K, d = x->c.d;
+            const int32_t *u = users + t, *p = pos + t, *n = neg + t;
+            void *buf; int32_t dt;
+            for (int k = 1; k < K; k++) {
+                if ((rc = lgcn_rs_phase(x, LGCN_RS_FWD, k, u, p, n, b, world, rank, nullptr, nullptr, stream))) return rc;
+                if ((rc = lgcn_rs_buffer(x, LGCN_RS_FWD, k, &buf, &dt))) return rc;
+                if ((rc = rs_exchange(api, dp, buf, dt, d, row_ranges, st))) return rc;
+            }
+            if ((rc = lgcn_rs_phase(x, LGCN_RS_BPR, 0, u, p, n, b, world, rank, nullptr, nullptr, stream))) return rc;
+            const int64_t S = (b + world - 1) / world, blk = 3 * S * d + 2 * S;
+            r = api->AllGather(x->c.contrib, gathered, (size_t)blk, ncclFloat32, dp->comm, st);
+            if (r != ncclSuccess) { lgcn_set_error("ncclAllGather failed"); return 11; }
+            if ((rc = lgcn_rs_phase(x, LGCN_RS_SCATTER, 0, u, p, n, b, world, rank, gathered, nullptr, stream))) return rc;
+            for (int k = K; k >= 1; k--) {
+                if ((rc = lgcn_rs_phase(x, LGCN_RS_BWD, k, u, p, n, b, world, rank, gathered, nullptr, stream))) return rc;
+                if ((rc = lgcn_rs_buffer(x, LGCN_RS_BWD, k, &buf, &dt))) return rc;
+                if ((rc = rs_exchange(api, dp, buf, dt, d, row_ranges, st))) return rc;
+            }
+            if ((rc = lgcn_rs_phase(x, LGCN_RS_FINISH, 0, u, p, n, b, world, rank, gathered, loss_out + 3 * i, stream))) return rc;
+        } else if (reduce == LGCN_DP_ROWS) {
             if ((rc = lgcn_train_step_dp_part1(x, users + t, pos + t, neg + t, b, world, rank, stream))) return rc;
             const int64_t S = (b + world - 1) / world, blk = 3 * S * x->c.d + 2 * S;
             r = api->AllGather(x->c.contrib, gathered, (size_t)blk, ncclFloat32, dp->comm, st);

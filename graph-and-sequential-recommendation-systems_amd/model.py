@@ -138,6 +138,8 @@ class LightGCN(nn.Module):
     def _drop_device_state(self):
         if self._dev is not None and self._dev.get('ctx'):
             _lib.load().lgcn_ctx_destroy(self._dev['ctx'])
+        if self._dev is not None and self._dev.get('graph_rs') is not None:
+            self._dev['graph_rs'].close()
         if self._dev is not None and self._dev.get('graph') is not None:
             self._dev['graph'].close()
         self._dev = None
@@ -149,7 +151,7 @@ class LightGCN(nn.Module):
         except Exception:
             pass
 
-    def _state(self, max_batch=None, need_ctx=False, dp_world=1):
+    def _state(self, max_batch=None, need_ctx=False, dp_world=1, row_subset=None):
         _lib.require_gpu()
         if not self._table.is_cuda:
             raise _lib.LgcnError("model parameters are not on the GPU: call .to(world.device) first")
@@ -168,6 +170,14 @@ class LightGCN(nn.Module):
                 'ctx': None, 'max_batch': 0,
             }
         st = self._dev
+        if row_subset is not None and st.get('graph_rs') is None:
+            # row-sharded propagation: the training context works on a plan of the owned rows only
+            # (same device CSR arrays); evaluation keeps the full plan
+            g = st['graph']
+            st['graph_rs'] = _lib.Graph(g.indptr, g.indices, g.vals, d_max=self.latent_dim,
+                                        row_order=np.ascontiguousarray(row_subset, np.int32))
+            if st['ctx'] is not None:
+                self._make_ctx(st['max_batch'], st.get('dp_world', 1))
         if need_ctx:
             max_batch = int(max_batch or self.config.get('bpr_batch_size', 2048))
             if st['ctx'] is None or st['max_batch'] < max_batch or st.get('dp_world', 1) != dp_world:
@@ -197,7 +207,7 @@ class LightGCN(nn.Module):
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
         cfg = _lib.TrainConfig()
-        cfg.graph = st['graph'].handle
+        cfg.graph = (st.get('graph_rs') or st['graph']).handle
         cfg.n_users, cfg.d, cfg.K = self.n_users, d, K
         cfg.act_dtype = act_dtype
         cfg.E0, cfg.adam_m, cfg.adam_v = self._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()

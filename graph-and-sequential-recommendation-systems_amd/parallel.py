@@ -46,6 +46,40 @@ def block_numel(B, world, d):
     return 3 * S * d + 2 * S
 
 
+def row_ranges(adj_indptr, n_users, world):
+    """Row-sharded propagation: rank r owns a contiguous range of user rows and a contiguous range of
+    item rows of the [N,d] tables, each range holding ~1/world of that block's non-zeros (the two
+    blocks of A_hat hold E non-zeros each, but a user row and an item row are differently long: one
+    range per block balances both).  -> int64 [world, 4] = (u_lo, u_hi, i_lo, i_hi), row ids."""
+    ip = np.asarray(adj_indptr, np.int64)
+    N = len(ip) - 1
+    out = np.zeros((world, 4), np.int64)
+    for col, lo, hi in ((0, 0, n_users), (2, n_users, N)):
+        base, total = ip[lo], ip[hi] - ip[lo]
+        cuts = np.searchsorted(ip[lo:hi + 1] - base, np.arange(world + 1) * (total / world), side='left') + lo
+        cuts[0], cuts[-1] = lo, hi
+        cuts = np.maximum.accumulate(cuts)
+        out[:, col], out[:, col + 1] = cuts[:-1], cuts[1:]
+    return out
+
+
+def owned_rows(ranges, rank):
+    u_lo, u_hi, i_lo, i_hi = (int(v) for v in ranges[rank])
+    return np.concatenate([np.arange(u_lo, u_hi, dtype=np.int32), np.arange(i_lo, i_hi, dtype=np.int32)])
+
+
+def exchange_rows(buf, ranges, group=None):
+    """The exchange after a row-sharded layer: every owner broadcasts its two row ranges of `buf`
+    [N,d] in place (torch.distributed form, used on CPU tensors over gloo in the tests; on the GPU the
+    library issues the same broadcasts itself as one RCCL group)."""
+    for q in range(len(ranges)):
+        src = dist.get_global_rank(group, q) if group is not None else q
+        for lo, hi in ((int(ranges[q][0]), int(ranges[q][1])), (int(ranges[q][2]), int(ranges[q][3]))):
+            if hi > lo:
+                dist.broadcast(buf[lo:hi], src=src, group=group)
+    return buf
+
+
 def exchange(local_block, group=None):
     """all-gather of one rank's [3*S*d | S | S] block -> [world * block] on every rank.
     Works on CUDA tensors over RCCL and on CPU tensors over gloo (tests)."""
@@ -77,9 +111,12 @@ class DataParallelBPR:
         self.reduce = reduce
         if shard not in ('batch', 'rows'):
             raise ValueError("shard must be 'batch' (replicated propagation) or 'rows' (row-sharded propagation)")
-        if shard == 'rows':
-            raise NotImplementedError("row-sharded propagation is not built yet")
         self.shard = shard
+        self.ranges = None
+        if shard == 'rows':
+            if reduce != 'rows':
+                raise ValueError("row-sharded propagation exchanges gradient rows (reduce='rows')")
+            self.ranges = row_ranges(recmodel._adj.indptr, recmodel.n_users, self.world)
         self._comm = None          # lgcn_dp handle: the library's own RCCL communicator (lazy)
         self._gathered = None
 
@@ -128,7 +165,8 @@ class DataParallelBPR:
         # one host call per epoch: the C loop issues kernels and RCCL collectives on one stream
         users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)
         st = m._state(max_batch=max(int(global_batch), int(m.config.get('bpr_batch_size', global_batch))), need_ctx=True,
-                      dp_world=self.world)
+                      dp_world=self.world,
+                      row_subset=owned_rows(self.ranges, self.rank) if self.shard == 'rows' else None)
         lib = _lib.load()
         lib.lgcn_ctx_set_lr(st['ctx'], float(self.opt.param_groups[0]['lr']))
         steps = (T + global_batch - 1) // global_batch
@@ -136,14 +174,18 @@ class DataParallelBPR:
         n = self.world * block_numel(global_batch, self.world, m.latent_dim)
         if self.reduce == 'rows' and (self._gathered is None or self._gathered.numel() < n):
             self._gathered = torch.empty(n, dtype=torch.float32, device=dev)
+        mode = 2 if self.shard == 'rows' else (0 if self.reduce == 'rows' else 1)
+        rr = np.ascontiguousarray(self.ranges, np.int64) if self.shard == 'rows' else None
         _lib.check(lib.lgcn_train_epoch_dp(st['ctx'], self._communicator(), _lib.tp(users), _lib.tp(pos), _lib.tp(neg), T,
-                                           int(global_batch), 0 if self.reduce == 'rows' else 1,
+                                           int(global_batch), mode, _lib.npp(rr) if rr is not None else None,
                                            _lib.tp(self._gathered) if self.reduce == 'rows' else None,
                                            _lib.tp(losses), _lib.current_stream()), "lgcn_train_epoch_dp")
         m._cache = None
         return losses
 
     def _step(self, users, pos, neg):
+        if self.shard == 'rows':
+            return self.train_epoch(users, pos, neg, int(len(users)))[0]
         m = self.model
         dev = m._table.device
         users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)

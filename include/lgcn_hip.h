@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 2
+#define LGCN_ABI_VERSION 3
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -100,14 +100,16 @@ int lgcn_build_norm_adj(int n_users, int m_items, const int64_t *r_indptr, const
  * range-checked here (rc 3), so no later launch can gather out of bounds.  Launches on one
  * graph share its scratch: the library orders them (a launch on another stream than the
  * previous one first waits for it).
- * row_order (DEVICE int32[n_rows], may be NULL) is an optional PROCESSING order of the rows
- * -- a permutation chosen for L2 locality; xcd_start (HOST int64[9], may be NULL) cuts that
- * order into the 8 slices the 8 XCDs work on (NULL: 8 slices of equal work).  Neither
- * changes the memory layout or any result bit.                                          */
+ * row_order (DEVICE int32[n_order], may be NULL = natural order of all rows) is an optional
+ * PROCESSING order of the rows -- a permutation chosen for L2 locality (n_order = n_rows), or
+ * a SUBSET of the rows without repetition (n_order < n_rows: launches then compute only those
+ * rows and leave the others of Y untouched -- a rank's share of a row-sharded job);
+ * xcd_start (HOST int64[9], may be NULL) cuts that order into the 8 slices the 8 XCDs work on
+ * (NULL: 8 slices of equal work).  Neither changes the memory layout or any result bit.   */
 typedef struct lgcn_graph lgcn_graph;   /* opaque */
 int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                       int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                      const int64_t *xcd_start, lgcn_graph **out);
+                      int64_t n_order, const int64_t *xcd_start, lgcn_graph **out);
 void lgcn_graph_destroy(lgcn_graph *g);
 
 /* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217
@@ -233,7 +235,7 @@ int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,
  * per process / GPU.  Rank 0 creates the 128-byte id (ncclGetUniqueId) and the caller hands it to
  * every rank through any channel it has (torch.distributed store, MPI, a file).             */
 #define LGCN_DP_ID_BYTES 128
-enum { LGCN_DP_ROWS = 0, LGCN_DP_DENSE = 1 };
+enum { LGCN_DP_ROWS = 0, LGCN_DP_DENSE = 1, LGCN_DP_ROW_SHARDED = 2 };
 typedef struct lgcn_dp lgcn_dp;   /* opaque */
 int lgcn_dp_available(void);                         /* 1 if RCCL could be resolved */
 int lgcn_dp_unique_id(void *id128);
@@ -245,10 +247,31 @@ int lgcn_dp_rank(const lgcn_dp *dp);
  * global batches (arrays identical on every rank); per batch: part 1, the collective on `stream`
  * (reduce = LGCN_DP_ROWS: ncclAllGather of cfg.contrib blocks into `gathered`
  * [world * (3*S*d + 2*S)] floats, S = ceil(B_global/world); LGCN_DP_DENSE: ncclAllReduce of G64 and
- * of the loss terms, `gathered` unused), part 2.  No host synchronisation.  loss_out: [3*steps]. */
+ * of the loss terms, `gathered` unused), part 2.  No host synchronisation.  loss_out: [3*steps].
+ * LGCN_DP_ROW_SHARDED: the row-sharded step below, every exchange one grouped in-place
+ * ncclBroadcast of the owners' row ranges; row_ranges = HOST int64[world][4] = {user rows lo, hi,
+ * item rows lo, hi} (row ids of the [N,d] tables) owned by each rank, else NULL.          */
 int lgcn_train_epoch_dp(lgcn_ctx *ctx, lgcn_dp *dp, const int32_t *users, const int32_t *pos,
                         const int32_t *neg, int64_t T, int32_t B_global, int32_t reduce,
-                        float *gathered, float *loss_out, void *stream);
+                        const int64_t *row_ranges, float *gathered, float *loss_out, void *stream);
+
+/* Row-sharded propagation (SURVEY 8e "beyond the contract"; analogue of the reference's A_split row
+ * folds, dataloader.py:192-201).  Tables stay replicated in layout; the graph handed to the context was
+ * created with row_order = ONLY the rows this rank owns (n_order < n_rows), so every SpMM phase
+ * computes 1/world of a layer and the owners' rows are exchanged before the next phase:
+ *   FWD k = 1..K-1   X_k[owned] = (A X_{k-1})[owned]                       -> exchange lgcn_rs_buffer(FWD,k)
+ *   BPR              this rank's batch shard -> cfg.contrib (as dp part 1)  -> all-gather of the blocks
+ *   SCATTER          all ranks' gradient rows -> G64 + row flags (every rank, identical)
+ *   BWD k = K..1     h_{k-1}[owned] = Gs + (A h_k)[owned]; k = 1: Adam on the owned rows
+ *                                                                          -> exchange lgcn_rs_buffer(BWD,k)
+ *   FINISH           zero the batch rows of G64 and their flags, reduce the loss
+ * Every row is computed by the same code in the same order wherever it runs, so the result is
+ * bitwise identical to lgcn_train_step.  Adam state (m, v) of a row lives on its owner only.   */
+enum { LGCN_RS_FWD = 0, LGCN_RS_BPR = 1, LGCN_RS_SCATTER = 2, LGCN_RS_BWD = 3, LGCN_RS_FINISH = 4 };
+int lgcn_rs_phase(lgcn_ctx *ctx, int32_t phase, int32_t k, const int32_t *users, const int32_t *pos,
+                  const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
+                  const float *gathered, float *loss_out, void *stream);
+int lgcn_rs_buffer(const lgcn_ctx *ctx, int32_t phase, int32_t k, void **buf, int32_t *dtype);
 
 /* reads and clears the device error flag (synchronises the stream): 0 = none,
  * 1 = id out of range in users/pos/neg.                                        */

@@ -709,3 +709,77 @@ def test_fused_eval_kernels_vs_torch_and_oracle(pkg, oracle, tiny, lastfm, tmp_p
     L = pkg._lib
     assert L.load().lgcn_eval_topk(L.tp(E), ds.n_users, ds.m_items, g.d, L.tp(ev.users32), len(ev.users), L.tp(ev.train_ptr),
                                    L.tp(ev.train_idx32), 33, L.tp(topk), None, L.current_stream()) == 3
+
+
+@pytest.mark.parametrize("which,world", [("tiny", 2), ("tiny", 3), ("lastfm", 4)])
+def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, which, world):
+    """Row-sharded propagation (SURVEY 8e "beyond the contract") emulated on one GPU: `world` training
+    contexts share ONE set of device buffers (what the in-place RCCL broadcasts of the owners' row ranges
+    produce on every rank) but each holds a graph plan of only its own rows; the phases of
+    include/lgcn_hip.h run rank after rank.  Three steps, tables + Adam state + losses identical to the
+    unsharded single-GPU step bit for bit; the owned ranges partition the rows and balance the non-zeros."""
+    g = tiny if which == "tiny" else lastfm
+    L, lib = pkg._lib, pkg._lib.load()
+    rng = np.random.Generator(np.random.PCG64(world))
+    B = 64
+    batches = [tuple(_dev(rng.integers(0, hi, b), torch.int32) for hi in (g.n_users, g.m_items, g.m_items)) for b in (B, B, 37)]
+    ds, ref = _make_model(pkg, g, tmp_path)
+    ref_losses = [ref.fused_step(*b).cpu().numpy().copy() for b in batches]
+    ds, m = _make_model(pkg, g, tmp_path)
+    adj = ds.getSparseGraphCSR()
+    ranges = pkg.parallel.row_ranges(adj.indptr, ds.n_users, world)
+    own = [pkg.parallel.owned_rows(ranges, r) for r in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(own)), np.arange(ds.n_users + ds.m_items))
+    nnz_r = np.array([np.diff(adj.indptr)[o].sum() for o in own], np.float64)
+    assert nnz_r.max() < 1.6 * nnz_r.mean()
+    st = m._state(max_batch=B, need_ctx=True, dp_world=world)          # buffers (shared by the emulated ranks)
+    full = st['graph']
+    graphs = [L.Graph(full.indptr, full.indices, full.vals, d_max=g.d, row_order=o) for o in own]
+    ctxs = []
+    for r in range(world):
+        cfg = L.TrainConfig()
+        cfg.graph = graphs[r].handle
+        cfg.n_users, cfg.d, cfg.K, cfg.act_dtype = ds.n_users, g.d, g.K, 0
+        cfg.E0, cfg.adam_m, cfg.adam_v = m._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
+        cfg.act, cfg.G64, cfg.bitmap = st['act'].data_ptr(), st['G64'].data_ptr(), st['bitmap'].data_ptr()
+        cfg.terms, cfg.ebuf, cfg.contrib = st['terms'].data_ptr(), st['ebuf'].data_ptr(), st['contrib'].data_ptr()
+        cfg.err, cfg.max_batch, cfg.decay = st['err'].data_ptr(), B, float(g.meta["decay"])
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = float(g.meta["lr"]), 0.9, 0.999, 1e-8, 1
+        h = C.c_void_p()
+        L.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "ctx")
+        ctxs.append(h)
+    K = g.K
+    FWD, BPR, SCATTER, BWD, FINISH = 0, 1, 2, 3, 4
+    stream = L.current_stream()
+    for i, (u, p, n) in enumerate(batches):
+        b = len(u)
+
+        def phase(r, ph, k, gathered=None, loss=None):
+            L.check(lib.lgcn_rs_phase(ctxs[r], ph, k, L.tp(u), L.tp(p), L.tp(n), b, world, r,
+                                      L.tp(gathered) if gathered is not None else None,
+                                      L.tp(loss) if loss is not None else None, stream), f"phase {ph} {k}")
+        for k in range(1, K):
+            for r in range(world):
+                phase(r, FWD, k)
+        nblk = pkg.parallel.block_numel(b, world, g.d)
+        blocks = []
+        for r in range(world):
+            phase(r, BPR, 0)
+            blocks.append(st['contrib'][:nblk].clone())
+        gathered = torch.cat(blocks)
+        phase(0, SCATTER, 0, gathered)                       # G64 / bitmap are shared: once
+        for k in range(K, 0, -1):
+            for r in range(world):
+                phase(r, BWD, k, gathered)
+        loss = torch.empty(3, device=DEV)
+        phase(0, FINISH, 0, gathered, loss)
+        torch.cuda.synchronize()
+        assert np.array_equal(loss.cpu().numpy().view(np.uint32), ref_losses[i].view(np.uint32)), (i, loss, ref_losses[i])
+    assert np.array_equal(m._table.cpu().numpy().view(np.uint32), ref._table.cpu().numpy().view(np.uint32))
+    for key in ('adam_m', 'adam_v'):
+        assert torch.equal(st[key], ref._dev[key])
+    assert int(st['G64'].abs().sum()) == 0 and int(st['bitmap'].abs().sum()) == 0
+    for h in ctxs:
+        lib.lgcn_ctx_destroy(h)
+    for gr in graphs:
+        gr.close()

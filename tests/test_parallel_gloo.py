@@ -97,3 +97,57 @@ def test_shard_bounds(pkg):
                 cover.extend(range(lo, hi))
             assert cover == list(range(B))
             assert par.block_numel(B, world, 64) == 3 * S * 64 + 2 * S
+
+
+def _rs_worker(rank, world, port, out):
+    """Row-sharded propagation over two gloo ranks: each rank computes ONLY the rows it owns of every
+    layer (oracle SpMM restricted to its row ranges), the owners' ranges are exchanged with
+    parallel.exchange_rows (the torch.distributed form of the library's grouped RCCL broadcasts), and
+    the K-layer mean must equal the oracle's single-process propagate() bit for bit on every rank."""
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG_NAME)
+    from oracle import oracle as orc
+    g = GoldenSet("lastfm")
+    ip, ix, vv = g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"]
+    par = pkg.parallel
+    ranges = par.row_ranges(ip, g.n_users, world)
+    mine = par.owned_rows(ranges, rank)
+    N = len(ip) - 1
+    sub_ip = np.concatenate([[0], np.cumsum(np.diff(ip)[mine])]).astype(np.int32)
+    sel = np.concatenate([np.arange(ip[r], ip[r + 1]) for r in mine]) if len(mine) else np.zeros(0, np.int64)
+    x = g.e0().copy()
+    acc = x.astype(np.float32).copy()
+    for _ in range(g.K):
+        y = torch.full((N, g.d), float("nan"))                  # rows of other owners: unknown until exchanged
+        y[torch.from_numpy(mine).long()] = torch.from_numpy(orc.spmm(sub_ip, ix[sel], vv[sel], x))
+        par.exchange_rows(y, ranges)
+        x = y.numpy()
+        acc = acc + x
+    out_mean = acc / np.float32(g.K + 1)
+    ref = orc.propagate(ip, ix, vv, g.e0(), g.K)
+    ok = bool(np.array_equal(out_mean.view(np.uint32), ref.view(np.uint32)))
+    t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(out, "w").write(str(int(t.item())))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_exchange_two_gloo_ranks(tmp_path):
+    out = os.path.join(str(tmp_path), "ok_rs.txt")
+    mp.spawn(_rs_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "1"
+
+
+def test_row_ranges_partition_and_balance(pkg, lastfm):
+    ip = lastfm.z["adj_indptr"].astype(np.int64)
+    N = len(ip) - 1
+    for world in (1, 2, 3, 8):
+        rr = pkg.parallel.row_ranges(ip, lastfm.n_users, world)
+        assert rr.shape == (world, 4) and rr[0, 0] == 0 and rr[-1, 1] == lastfm.n_users and rr[0, 2] == lastfm.n_users and rr[-1, 3] == N
+        assert np.array_equal(rr[1:, 0], rr[:-1, 1]) and np.array_equal(rr[1:, 2], rr[:-1, 3])
+        own = np.concatenate([pkg.parallel.owned_rows(rr, r) for r in range(world)])
+        assert np.array_equal(np.sort(own), np.arange(N))
+        nnz = np.array([(ip[rr[r, 1]] - ip[rr[r, 0]]) + (ip[rr[r, 3]] - ip[rr[r, 2]]) for r in range(world)], np.float64)
+        assert nnz.max() <= 1.3 * nnz.mean() + 2 * np.diff(ip).max()
