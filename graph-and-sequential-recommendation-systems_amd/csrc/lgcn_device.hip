@@ -342,7 +342,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
             //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
-            //  k_bpr_loss of the next step zeroes the stale one with plain stores)
+            //  k_rows of the next step zeroes the stale one with plain stores)
             i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
 #pragma unroll
             for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
@@ -578,18 +578,16 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// BPR on the batch, two launches (the fused one-workgroup-per-triplet form kept a CU at 2
-// resident workgroups and took 30 us; split, every slot row is its own small workgroup).
+// BPR on the batch, ONE launch (a one-workgroup-per-triplet form kept a CU at 2 resident workgroups and
+// took 30 us: every slot row is its own small workgroup, and the triplet's third slot to finish does the
+// triplet's loss).
 //
 // k_rows: one 256-thread workgroup per slot (3B slots: user, positive item, negative item of
 //   every triplet).  e = mean_k X_k[row]; the last layer X_K[row] = (A_hat X_{K-1})[row] is
 //   computed on the fly.  The 4 waves split the row's 64-entry tiles (positives are sampled
 //   proportionally to popularity: 1000-neighbour rows are common); a wave without work ends
 //   at once (s_barrier counts only surviving waves), so a typical slot costs one wave.
-// k_bpr_loss: one lane group per triplet: x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
-//   r = |e_u|^2+|e_p|^2+|e_n|^2 ; the three gradient rows w.r.t. the propagated table
-//    -> fixed-point atomics into G64 + bitmap flag (single GPU) or the
-//   exchange buffer (data parallel).
+//   Then triplet_loss (below) on the last of a triplet's three slots to arrive.
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -608,6 +606,7 @@ struct BprArgs {
     float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
     int32_t terms_off, terms_stride;
     int32_t *err;
+    int32_t *tickets;     // [B_local] arrivals of a triplet's three slots (zero between steps)
 };
 
 __device__ __forceinline__ float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
@@ -629,75 +628,24 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
     return u < 0 || u >= a.n_users || p < 0 || (int64_t)p + a.n_users >= a.N || n < 0 || (int64_t)n + a.n_users >= a.N;
 }
 
-#ifndef BPR_BW
-#define BPR_BW 4
-#endif
-#ifndef ROWS_MIN_TILES
-#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
-#endif
-// TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
-template <int D, typename TG, typename TI>
-__device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int64_t row, int s0, int s1, int q, int nparts,
-                                          int lane, int2 *stage, float (*part)[D]) {
-    typedef Geo<D, TG, false> G;
-    constexpr int C = G::CPL, LPR = G::LPR;
-    GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
-    typename G::Acc xk = row_gather<D, TG, false>(a.indices, a.vals, s0, s1, src, lane, stage);
-    if (nparts > 1) {
-        if (lane < LPR) storev<C>(&part[q][lane * C], xk);
-        __syncthreads();
-        if (q != 0) return;
-        if (lane < LPR) {
-            xk = loadv<C>(&part[0][lane * C]);
-            for (int w = 1; w < nparts; w++) xk += loadv<C>(&part[w][lane * C]);
-        }
-    }
-    if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
-        const int64_t off = row * D + lane * C;
-        typename G::Acc s = loadv<C>(a.X0 + off);
-        for (int k = 1; k < a.K; k++) s += loadv<C>((const TI *)a.Xl[k] + off);
-        s += xk;
-        const float div = (float)(a.K + 1);
-        storev<C>(a.ebuf + (int64_t)blockIdx.x * D + lane * C, s / div);
-    }
-}
-
-template <int D, typename TI>
-__global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
-    __shared__ int2 stage_lds[BPR_BW][64];
-    __shared__ __attribute__((aligned(32))) float part_lds[BPR_BW][D];
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
-    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
-    if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
-    const int start = a.indptr[row], end = a.indptr[row + 1];
-    const int tiles = (end - start + 63) >> 6, per = max((tiles + BPR_BW - 1) / BPR_BW, ROWS_MIN_TILES);
-    const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
-    if (q >= nparts) return;
-    const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
-    if (a.K == 1) rows_body<D, float, TI>(a, a.X0, row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
-    else rows_body<D, TI, TI>(a, a.Xl[a.K - 1], row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
-}
-
-// Lane = column (mod 64): every load, store and atomic wave-instruction of a triplet covers
-// min(D,64) contiguous elements -- 512 contiguous bytes per 64-bit atomic instruction at d=64.
-// (With 4 columns per lane the same atomics were 16 lanes x 8 B at a 32-byte stride and cost
-// 9 of this kernel's 13.7 us.)
+// Loss terms and the three gradient rows of ONE triplet by one wave.  Lane = column (mod 64): every
+// load, store and atomic wave-instruction covers min(D,64) contiguous elements -- 512 contiguous bytes
+// per 64-bit atomic instruction at d = 64.  (With 4 columns per lane the same atomics were 16 lanes x 8 B
+// at a 32-byte stride and cost 9 of a 13.7 us kernel.)  x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
+// r = |e_u|^2+|e_p|^2+|e_n|^2 ; gradient rows w.r.t. the propagated table -> fixed-point
+// atomics into G64 + row flags (single GPU / dense DP) or the exchange block (DP rows).
 template <int D>
-__global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
-    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT, TPB = 256 / LPT;     // lanes per triplet, columns per lane
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
-        a.stale_bitmap[i] = 0u;
-    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
-    if (b >= a.B_local) return;                 // whole lane groups leave together
+__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int lane) {
+    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
+    if (lane >= LPT) return;
+    const int l = lane;
     float u[CPL], p[CPL], n[CPL];
     float ps = 0.f, ns = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
 #pragma unroll
-    for (int j = 0; j < CPL; j++) {
-        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
-        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
-        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
+    for (int j = 0; j < CPL; j++) {        // sc1 loads: the rows were written through by other workgroups
+        u[j] = __hip_atomic_load(a.ebuf + ((int64_t)0 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p[j] = __hip_atomic_load(a.ebuf + ((int64_t)1 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n[j] = __hip_atomic_load(a.ebuf + ((int64_t)2 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ps += u[j] * p[j]; ns += u[j] * n[j]; ru += u[j] * u[j]; rp += p[j] * p[j]; rn += n[j] * n[j];
     }
     float rr = ru + rp + rn;
@@ -730,6 +678,78 @@ __global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
         }
         if (a.G64 && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
     }
+}
+
+#ifndef BPR_BW
+#define BPR_BW 4
+#endif
+#ifndef ROWS_MIN_TILES
+#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
+#endif
+// TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
+template <int D, typename TG, typename TI>
+__device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int64_t row, int s0, int s1, int q, int nparts,
+                                          int lane, int2 *stage, float (*part)[D]) {
+    typedef Geo<D, TG, false> G;
+    constexpr int C = G::CPL, LPR = G::LPR;
+    GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
+    typename G::Acc xk = row_gather<D, TG, false>(a.indices, a.vals, s0, s1, src, lane, stage);
+    if (nparts > 1) {
+        if (lane < LPR) storev<C>(&part[q][lane * C], xk);
+        __syncthreads();
+        if (q != 0) return;
+        if (lane < LPR) {
+            xk = loadv<C>(&part[0][lane * C]);
+            for (int w = 1; w < nparts; w++) xk += loadv<C>(&part[w][lane * C]);
+        }
+    }
+    // The slot's row is published WRITE-THROUGH (sc1), the wave drains and takes the triplet's ticket: the
+    // third of a triplet's three slots to arrive computes the triplet's loss and gradient rows right here
+    // (same hand-off as the long-row partials: sc1 stores -> vmcnt(0) -> agent-scope ticket; the last
+    // arriver acquires and reads with sc1 loads).  No separate loss kernel, no kernel boundary.
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
+        const int64_t off = row * D + lane * C;
+        typename G::Acc s = loadv<C>(a.X0 + off);
+        for (int k = 1; k < a.K; k++) s += loadv<C>((const TI *)a.Xl[k] + off);
+        s += xk;
+        const float div = (float)(a.K + 1);
+        union { typename G::Acc v; unsigned long long q[C / 2]; } pk; pk.v = s / div;
+        gu64 *dst = (gu64 *)(a.ebuf + (int64_t)blockIdx.x * D + lane * C);
+#pragma unroll
+        for (int i = 0; i < C / 2; i++) __hip_atomic_store(dst + i, pk.q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int b = blockIdx.x % a.B_local;
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != 2) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(a.tickets + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next step
+    triplet_loss<D>(a, b, lane);
+}
+
+template <int D, typename TI>
+__global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
+    __shared__ int2 stage_lds[BPR_BW][64];
+    __shared__ __attribute__((aligned(32))) float part_lds[BPR_BW][D];
+    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
+    for (int64_t i = (int64_t)blockIdx.x * (64 * BPR_BW) + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * (64 * BPR_BW))
+        a.stale_bitmap[i] = 0u;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
+    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
+    if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
+    const int start = a.indptr[row], end = a.indptr[row + 1];
+    const int tiles = (end - start + 63) >> 6, per = max((tiles + BPR_BW - 1) / BPR_BW, ROWS_MIN_TILES);
+    const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
+    if (q >= nparts) return;
+    const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
+    if (a.K == 1) rows_body<D, float, TI>(a, a.X0, row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
+    else rows_body<D, TI, TI>(a, a.Xl[a.K - 1], row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
 }
 
 // slot -> destination row of the global batch (-1: the slot's triplet has a bad id)
@@ -1119,7 +1139,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!cfg || !out) { lgcn_set_error("lgcn_ctx_create: null argument"); return 3; }
     const lgcn_train_config &c = *cfg;
     if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
-        !c.bitmap || !c.terms || !c.ebuf || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
+        !c.bitmap || !c.terms || !c.ebuf || !c.err || !c.tickets) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
     if (c.K > 1 && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
@@ -1177,18 +1197,16 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
     a.terms_off = atomics ? b_off : 0; a.terms_stride = B_global;
-    a.ebuf = c.ebuf;
+    a.ebuf = c.ebuf; a.tickets = c.tickets;
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
-        // two steps ago still has to be cleared (k_bpr_loss does it on the other ranks)
+        // two steps ago still has to be cleared (k_rows does it on the other ranks)
         HIP_OK(hipMemsetAsync(a.stale_bitmap, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
         return 0;
     }
     DISPATCH_D(c.d, {
         if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
         else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
-        const int tpb = 256 / (D < 64 ? D : 64);
-        hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
     });
     return 0;
 }

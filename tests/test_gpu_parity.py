@@ -744,6 +744,7 @@ def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, 
         cfg.act, cfg.G64, cfg.bitmap = st['act'].data_ptr(), st['G64'].data_ptr(), st['bitmap'].data_ptr()
         cfg.terms, cfg.ebuf, cfg.contrib = st['terms'].data_ptr(), st['ebuf'].data_ptr(), st['contrib'].data_ptr()
         cfg.err, cfg.max_batch, cfg.decay = st['err'].data_ptr(), B, float(g.meta["decay"])
+        cfg.tickets = st['tickets'].data_ptr()
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = float(g.meta["lr"]), 0.9, 0.999, 1e-8, 1
         h = C.c_void_p()
         L.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "ctx")
