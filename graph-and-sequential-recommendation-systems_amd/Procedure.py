@@ -27,10 +27,18 @@ CORES = multiprocessing.cpu_count() // 2
 def sample_epoch_to_device(dataset, device):
     """Sample (utils.UniformSample_original), upload, shuffle (utils.shuffle) -- the
     semantics of main.py:216-220.  Returns int32 device tensors users, pos, neg [T]."""
-    S = utils.UniformSample_original(dataset)
-    T = len(S)
-    perm = utils.shuffle_indices(T)
-    S32 = torch.from_numpy(np.ascontiguousarray(S[:, :3], dtype=np.int32)).to(device)
+    if (torch.device(device).type == 'cuda' and int(world.config.get('gpu_sampler', 1)) and utils.sample_ext
+            and utils.sampler_mode(dataset) == 'cpp'):
+        # the native sampler's stream and rows, produced on the device (sampling.cpp:27-56, bit-exact)
+        S32 = utils.sampling.sample_negative_device(dataset.n_users, dataset.m_items, dataset.trainDataSize,
+                                                    utils._pos_csr(dataset), device)
+        T = int(S32.shape[0])
+        perm = utils.shuffle_indices(T)
+    else:
+        S = utils.UniformSample_original(dataset)
+        T = len(S)
+        perm = utils.shuffle_indices(T)
+        S32 = torch.from_numpy(np.ascontiguousarray(S[:, :3], dtype=np.int32)).to(device)
     permd = torch.from_numpy(perm).to(device)
     users = torch.empty(T, dtype=torch.int32, device=device)
     pos = torch.empty_like(users)

@@ -41,6 +41,8 @@ SIGNATURES = {
     "lgcn_sampling_randint": (C.c_int, [C.c_int]),
     "lgcn_sample_negative": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_int, _vp]),
     "lgcn_sample_negative_by_user": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "lgcn_sample_negative_device_workspace": (C.c_int64, [C.c_int, C.c_int64]),
+    "lgcn_sample_negative_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "lgcn_np_seed": (None, [C.c_uint32]),
     "lgcn_sample_python": (C.c_int64, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp]),
     "lgcn_np_shuffle_perm": (C.c_int, [C.c_int64, _vp]),

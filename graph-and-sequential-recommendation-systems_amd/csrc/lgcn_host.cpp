@@ -46,6 +46,48 @@ public:
     }
     inline int below(int end) { return next() % end; }     // sampling.cpp:22-25
 
+    // The generator is the linear recurrence x[n] = x[n-3] + x[n-31] over Z/2^32; its state is the
+    // history h[j] = x[n-31+j], j = 0..30 (oldest first).  One step maps h to (h[1..30], h[0]+h[28]), a
+    // 31 x 31 matrix M over Z/2^32 -- so n steps are M^n, computed by squaring: the stream can be
+    // entered at any position without walking there (the GPU sampler expands blocks of it in
+    // parallel from their start histories, and the host generator is moved past what the GPU used).
+    void history(uint32_t h[31]) const { for (int j = 0; j < kDeg; j++) h[j] = ring_[(front_ + j) % kDeg]; }
+    void set_history(const uint32_t h[31]) { for (int j = 0; j < kDeg; j++) ring_[j] = h[j]; front_ = 0; rear_ = kDeg - kSep; }
+    struct Mat { uint32_t a[31][31]; };
+    static Mat step_matrix() {
+        Mat m; std::memset(&m, 0, sizeof m);
+        for (int j = 0; j < kDeg - 1; j++) m.a[j][j + 1] = 1;
+        m.a[kDeg - 1][0] = 1; m.a[kDeg - 1][kDeg - kSep] = 1;
+        return m;
+    }
+    static Mat mul(const Mat &x, const Mat &y) {
+        Mat r; std::memset(&r, 0, sizeof r);
+        for (int i = 0; i < kDeg; i++)
+            for (int k = 0; k < kDeg; k++) {
+                const uint32_t xv = x.a[i][k];
+                if (!xv) continue;
+                for (int j = 0; j < kDeg; j++) r.a[i][j] += xv * y.a[k][j];
+            }
+        return r;
+    }
+    static Mat power(uint64_t n) {            // M^n
+        Mat r; std::memset(&r, 0, sizeof r);
+        for (int i = 0; i < kDeg; i++) r.a[i][i] = 1;
+        Mat b = step_matrix();
+        for (; n; n >>= 1) { if (n & 1) r = mul(b, r); b = mul(b, b); }
+        return r;
+    }
+    static void apply(const Mat &m, const uint32_t in[31], uint32_t out[31]) {
+        for (int i = 0; i < kDeg; i++) { uint32_t acc = 0; for (int j = 0; j < kDeg; j++) acc += m.a[i][j] * in[j]; out[i] = acc; }
+    }
+    void jump(uint64_t n) {                   // as if next() had been called n times
+        uint32_t h[31], o[31];
+        history(h);
+        const Mat m = power(n);
+        apply(m, h, o);
+        set_history(o);
+    }
+
 private:
     static constexpr int kDeg = 31, kSep = 3;
     uint32_t ring_[kDeg];
@@ -194,6 +236,21 @@ int lgcn_sample_negative_by_user(const int32_t *users, int n_listed, int item_nu
     }
     return 0;
 }
+
+// ---- glibc stream access for the GPU sampler (csrc/lgcn_sampler.hip)
+// start histories of `nblocks` consecutive blocks of `block_len` draws, beginning at the generator's
+// current position: out[b*31 + j]
+void lgcn_glibc_block_histories(int64_t nblocks, int64_t block_len, uint32_t *out) {
+    uint32_t h[31], o[31];
+    g_rand.history(h);
+    const GlibcRand::Mat m = GlibcRand::power((uint64_t)block_len);
+    for (int64_t b = 0; b < nblocks; b++) {
+        std::memcpy(out + b * 31, h, sizeof h);
+        GlibcRand::apply(m, h, o);
+        std::memcpy(h, o, sizeof h);
+    }
+}
+void lgcn_glibc_advance(uint64_t n) { g_rand.jump(n); }
 
 void lgcn_np_seed(uint32_t seed) { g_np.seed(seed); }
 

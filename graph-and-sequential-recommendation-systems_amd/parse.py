@@ -66,6 +66,8 @@ def build_parser():
                    help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
     p.add_argument('--prefetch_epoch', type=int, default=0,
                    help='NEW: 1 = sample/shuffle/upload epoch e+1 while epoch e runs on the GPU')
+    p.add_argument('--gpu_sampler', type=int, default=1,
+                   help='NEW: 1 = the cpp-mode BPR sampler runs on the GPU (same rand() stream, same rows); 0 = on the host')
     p.add_argument('--eval_fused', type=int, default=1,
                    help='NEW: 1 = Procedure.Test through the fused HIP kernels (MFMA scores + mask + top-k, metrics on device); '
                         '0 = torch matmul/topk harness')

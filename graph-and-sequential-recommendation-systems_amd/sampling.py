@@ -52,3 +52,29 @@ def sample_negative_ByUser(users, item_num, allPos, neg_num):
                                                         _lib.npp(indptr), _lib.npp(indices), int(neg_num),
                                                         _lib.npp(S)), "sampling.sample_negative_ByUser")
     return S
+
+
+_DEVICE_CSR = {}          # id(indptr array) -> (device indptr, device indices, workspace)
+
+
+def sample_negative_device(user_num, item_num, train_num, allPos, device):
+    """NEW: sample_negative (neg_num = 1) on the GPU -- the same int32 rows from the same rand()
+    stream, returned as a DEVICE tensor [user_num*(train_num//user_num), 3] (no host loop, no upload)."""
+    import torch
+    indptr, indices = _csr_of(allPos)
+    key = (indptr.ctypes.data, indices.ctypes.data, str(device))
+    ent = _DEVICE_CSR.get(key)
+    lib = _lib.load()
+    if ent is None:
+        ws = int(lib.lgcn_sample_negative_device_workspace(int(user_num), int(train_num)))
+        ent = (torch.from_numpy(indptr).to(device), torch.from_numpy(indices).to(device),
+               torch.empty(max(ws, 256), dtype=torch.uint8, device=device), indptr, indices)
+        _DEVICE_CSR.clear()
+        _DEVICE_CSR[key] = ent
+    d_ip, d_ix, work = ent[:3]
+    T = int(user_num) * (int(train_num) // int(user_num))
+    S = torch.empty(T, 3, dtype=torch.int32, device=device)
+    _lib.check(lib.lgcn_sample_negative_device(int(user_num), int(item_num), int(train_num), _lib.npp(indptr),
+                                               _lib.tp(d_ip), _lib.tp(d_ix), _lib.tp(S), _lib.tp(work), int(work.numel()),
+                                               _lib.current_stream()), "sampling.sample_negative_device")
+    return S

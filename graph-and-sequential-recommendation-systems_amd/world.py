@@ -100,6 +100,7 @@ def configure(argv=None):
     config['row_order'] = args.row_order
     config['prefetch_epoch'] = args.prefetch_epoch
     config['eval_fused'] = args.eval_fused
+    config['gpu_sampler'] = args.gpu_sampler
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

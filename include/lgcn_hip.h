@@ -58,6 +58,16 @@ int lgcn_sample_negative_by_user(const int32_t *users, int n_users_listed, int i
                                  const int64_t *indptr, const int32_t *indices,
                                  int neg_num, int32_t *S_out);
 
+/* The same sampler on the GPU (neg_num = 1): identical rows from the identical rand() stream, written
+ * to DEVICE memory (d_S int32 [user_num*(train_num/user_num), 3]); the host generator is then moved
+ * past the draws the device consumed (jump-ahead), so host and device calls can be mixed freely.
+ * h_indptr: host copy of the CSR row pointers (degree checks); d_indptr/d_indices: device CSR;
+ * workspace: device bytes from lgcn_sample_negative_device_workspace().  Synchronises `stream`. */
+int64_t lgcn_sample_negative_device_workspace(int user_num, int64_t train_num);
+int lgcn_sample_negative_device(int user_num, int item_num, int64_t train_num,
+                                const int64_t *h_indptr, const int64_t *d_indptr, const int32_t *d_indices,
+                                int32_t *d_S, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* numpy legacy global RandomState stream (MT19937), used by the reference for
  * the fallback sampler and the epoch shuffle.                                 */
 /* utils.set_seed -> np.random.seed(seed)                    utils.py:114-120 */
