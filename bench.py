@@ -108,6 +108,15 @@ def read_traffic(key, lib_hash):
     return rec.get("bytes"), rec.get("source")
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """stderr progress line (a multi-minute setup must not look hung to a watchdog)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +188,7 @@ def main():
     import io
     import contextlib
     t_setup = time.perf_counter()
+    progress(f"workload {a.workload}: building the dataset")
     with contextlib.redirect_stdout(io.StringIO()):
         if a.workload == "gowalla" and os.path.exists(GOWALLA_NPZ):
             data_dir = materialize_gowalla(GOWALLA_NPZ, os.path.join(a.data_dir, f"gowalla_r{rank}"))
@@ -188,9 +198,13 @@ def main():
             ds = synthetic_dataset(pkg, a.workload, w.config, dev)
             data_kind = ("synthetic power-law bipartite graph of the configured shape (synthetic.py, seed 2020); "
                          "random-init weights, seed 2020")
+        progress(f"interactions ready ({ds.trainDataSize} edges); normalised adjacency + model init")
+        ds.getSparseGraphCSR()
+        progress("adjacency built")
         pkg.sampling.seed(2020)
         pkg.utils.set_seed(2020)
         model = pkg.model.LightGCN(w.config, ds).to(dev)
+    progress("model on the device")
     N = ds.n_users + ds.m_items
     nnz = int(ds.getSparseGraphCSR().nnz)
     s = 4 if a.act_dtype == "fp32" else 2
@@ -250,6 +264,7 @@ def main():
                                                 ds.pos_csr(), 1)
         users, pos, neg = (torch.from_numpy(np.ascontiguousarray(S[:, c])).to(dev) for c in range(3))
     setup_s = time.perf_counter() - t_setup
+    progress(f"{need} triplets resident; warm-up ({a.warmup} steps)")
 
     if not use_dp:
         def run(lo, steps):
@@ -267,6 +282,7 @@ def main():
 
     run(0, a.warmup)
     barrier()
+    progress(f"timed region ({a.steps} steps)")
     t0 = time.perf_counter()
     losses = run(a.warmup * Bg, a.steps)
     barrier()
@@ -275,6 +291,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    progress(f"timed region done: {dt:.3f} s")
     model.check_device_errors()
     first_loss = float(losses.reshape(-1, 3)[0, 0])
     last_loss = float(losses.reshape(-1, 3)[-1, 0])

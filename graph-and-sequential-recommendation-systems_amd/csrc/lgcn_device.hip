@@ -317,7 +317,6 @@ struct SpmmArgs {
     LongPlan lp; SlicePlan sp;
     const void *X; void *Y;
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
-    int32_t bm_words;             // > 0: the kernel copies the bitmap into LDS (dynamic shared memory) first
     float *P; float *M; float *V;
     bf16_t *Pb;                   // optional bf16 shadow of P written by the Adam epilogue
     // last kernel of a step (K >= 2): its epilogue zeroes the G64 rows / bitmap bits it consumes and one
@@ -431,18 +430,12 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
     constexpr int U = SP ? 4 : SPMM_U;
     __shared__ int2 stage_lds[4][NPW * ST];
-    extern __shared__ uint32_t bm_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
     src.X = SP ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
-    if (SP && a.bm_words > 0) {
-        // the bitmap test of every neighbour is a dependent round trip when it goes to L2; the whole
-        // bitmap of a <= 131 k-row graph is <= 16 KiB: copy it into LDS once per workgroup
-        for (int i = threadIdx.x; i < a.bm_words; i += 256) bm_lds[i] = a.bitmap[i];
-        __syncthreads();
-        src.bm = bm_lds;
-    }
+    // (a per-workgroup LDS copy of the row bitmap -- 9 KiB on Gowalla -- was measured: no gain, the copy's
+    //  own round trip per workgroup costs what the per-neighbour tests save once a pack's tests are batched)
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
     //  sat on the tail and cost +25 us)
     if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == 3)
@@ -824,9 +817,8 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
-#define BM_LDS_MAX_WORDS 4096     /* 16 KiB: with the 2 KiB stage, 8 workgroups still fit a CU's 160 KiB */
 template <int D, typename TI, typename TO, int MODE>
-static void launch_spmm_t(SpmmArgs a, int64_t bm_words, hipStream_t st) {
+static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     constexpr int RPB = PackGeo<Geo<D, TI, (MODE & M_SPARSE) != 0>::NPW>::RPB;
     static_assert(SLICE_PAD % RPB == 0, "slice padding must hold whole workgroups of every variant");
     unsigned grid = 0, widest = 0;
@@ -836,31 +828,27 @@ static void launch_spmm_t(SpmmArgs a, int64_t bm_words, hipStream_t st) {
     }
     if (a.remap) grid = widest * XCDS;
     if (grid == 0) return;
-    size_t dyn = 0;
-    a.bm_words = 0;
-    static const bool bm_lds = getenv("LGCN_BM_LDS") && atoi(getenv("LGCN_BM_LDS")) != 0;     // experiment switch
-    if ((MODE & M_SPARSE) && bm_lds && bm_words > 0 && bm_words <= BM_LDS_MAX_WORDS) { a.bm_words = (int32_t)bm_words; dyn = 4 * (size_t)bm_words; }
-    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), dyn, st, a);
+    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), 0, st, a);
 }
 
 template <int D, int MODE>
-static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, int64_t bm_words, hipStream_t st) {
+static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, hipStream_t st) {
     if (MODE & M_SPARSE) x_dtype = LGCN_F32;           // source is the fixed-point table; TI unused
     if (MODE & M_ADAM) y_dtype = LGCN_F32;
-    if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, bm_words, st);
-    else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, bm_words, st);
-    else if (x_dtype == LGCN_BF16 && y_dtype == LGCN_F32) launch_spmm_t<D, bf16_t, float, MODE>(a, bm_words, st);
-    else launch_spmm_t<D, bf16_t, bf16_t, MODE>(a, bm_words, st);
+    if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, st);
+    else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, st);
+    else if (x_dtype == LGCN_BF16 && y_dtype == LGCN_F32) launch_spmm_t<D, bf16_t, float, MODE>(a, st);
+    else launch_spmm_t<D, bf16_t, bf16_t, MODE>(a, st);
     return 0;
 }
 
 template <int MODE>
-static int launch_spmm(const SpmmArgs &a, int d, int x_dtype, int y_dtype, hipStream_t st, int64_t bm_words = 0) {
+static int launch_spmm(const SpmmArgs &a, int d, int x_dtype, int y_dtype, hipStream_t st) {
     switch (d) {
-    case 32: return launch_spmm_d<32, MODE>(a, x_dtype, y_dtype, bm_words, st);
-    case 64: return launch_spmm_d<64, MODE>(a, x_dtype, y_dtype, bm_words, st);
-    case 128: return launch_spmm_d<128, MODE>(a, x_dtype, y_dtype, bm_words, st);
-    case 256: return launch_spmm_d<256, MODE>(a, x_dtype, y_dtype, bm_words, st);
+    case 32: return launch_spmm_d<32, MODE>(a, x_dtype, y_dtype, st);
+    case 64: return launch_spmm_d<64, MODE>(a, x_dtype, y_dtype, st);
+    case 128: return launch_spmm_d<128, MODE>(a, x_dtype, y_dtype, st);
+    case 256: return launch_spmm_d<256, MODE>(a, x_dtype, y_dtype, st);
     }
     lgcn_set_error("embedding dim must be 32, 64, 128 or 256");
     return 3;
@@ -1253,8 +1241,8 @@ static int backward_layer(lgcn_ctx *x, int k, int32_t B, const float *gathered, 
         }
     }
     const int prev_dt = first ? LGCN_F32 : c.act_dtype;
-    if (first && last) return launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st, x->bm_words);
-    if (first) return launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st, x->bm_words);
+    if (first && last) return launch_spmm<M_SPARSE | M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
+    if (first) return launch_spmm<M_SPARSE | M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
     if (last) return launch_spmm<M_ADDG | M_ADAM>(a, c.d, prev_dt, LGCN_F32, st);
     return launch_spmm<M_ADDG>(a, c.d, prev_dt, c.act_dtype, st);
 }
