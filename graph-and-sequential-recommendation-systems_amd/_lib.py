@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -25,7 +25,7 @@ class TrainConfig(C.Structure):
         ("n_users", C.c_int32), ("d", C.c_int32), ("K", C.c_int32), ("act_dtype", C.c_int32),
         ("E0", _vp), ("adam_m", _vp), ("adam_v", _vp),
         ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("ebuf", _vp), ("contrib", _vp),
-        ("err", _vp), ("tickets", _vp), ("max_batch", C.c_int32),
+        ("err", _vp), ("max_batch", C.c_int32),
         ("decay", C.c_float),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
         ("xcd_remap", C.c_int32), ("reserved", C.c_int32),

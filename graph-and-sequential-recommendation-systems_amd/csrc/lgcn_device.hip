@@ -247,20 +247,30 @@ __device__ __forceinline__ Acc reduce_groups(Acc acc) {
     return acc;   // every lane group holds the full sum for its columns
 }
 
-template <int D, typename TI, bool SPARSE>
+// where a wave reads the (col,val) pairs of a row segment from: the CSR arrays (two 4-byte loads per
+// entry) or the graph plan's packed stream (one 8-byte load)
+struct CsrSrc {
+    const int32_t *indices; const float *vals;
+    __device__ __forceinline__ int2 at(int64_t i) const { return make_int2(indices[i], __float_as_int(vals[i])); }
+};
+struct PackedSrc {
+    const int2 *pk;
+    __device__ __forceinline__ int2 at(int64_t i) const { return pk[i]; }
+};
+
+template <int D, typename TI, bool SPARSE, typename ES>
 __device__ __forceinline__ typename Geo<D, TI, SPARSE>::Acc
-row_gather(const int32_t *__restrict__ indices, const float *__restrict__ vals, int start, int end,
-           const GatherSrc &src, int lane, int2 *stage) {
+row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int lane, int2 *stage) {
     typedef Geo<D, TI, SPARSE> G;
     typename G::Acc acc = zerov<G::CPL>();
-    // the next tile's (col,val) pair is in flight while this tile gathers
-    int col = 0; float val = 0.f;
-    if (start + lane < end) { col = indices[start + lane]; val = vals[start + lane]; }
-    for (int base = start; base < end; base += 64) {
-        const int n = min(64, end - base);
-        const int cnt = tile_stage<SPARSE>(col, val, n, src, lane, stage);
+    // the next tile's (col,val) pairs are in flight while this tile gathers
+    int2 cv = make_int2(0, 0);
+    if (start + lane < end) cv = es.at(start + lane);
+    for (int64_t base = start; base < end; base += 64) {
+        const int n = (int)min((int64_t)64, end - base);
+        const int cnt = tile_stage<SPARSE>(cv.x, __int_as_float(cv.y), n, src, lane, stage);
         __builtin_amdgcn_wave_barrier();
-        if (base + 64 + lane < end) { col = indices[base + 64 + lane]; val = vals[base + 64 + lane]; }
+        if (base + 64 + lane < end) cv = es.at(base + 64 + lane);
         tile_gather<D, TI, SPARSE>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
     }
@@ -298,8 +308,14 @@ row_gather(const int32_t *__restrict__ indices, const float *__restrict__ vals, 
 #define LONG_CH 512           /* measured on Gowalla: 64 -> 58 us, 128 -> 40, 256 -> 34, 512 -> 32.5, 768 -> 39, none -> 57 */
 #endif
 #define XCDS 8
+// The (col,val) pairs of the planned rows are kept a second time as ONE packed stream of 8-byte entries in
+// plan order (chunks of a slice, then its short rows): the rows of a pack are contiguous there, so a wave
+// loads a whole pack's index tiles with one or two 512-byte instructions instead of two 4-byte loads per
+// row.  What bounds these kernels is the number of vector-memory instructions a CU retires (a 13-lane index
+// load holds its address/return path as long as a 64-lane 1-KiB row gather, 26-30 cycles per instruction
+// measured on both the fp32 and the bf16 table), so every instruction saved is time saved.
 struct LongPlan {
-    const int4 *chunks;           // [n_chunk_slots] (index o into long_row | -1 = padding, first nnz, end nnz, ordinal in row)
+    const int4 *chunks;           // [n_chunk_slots] (index o into long_row | -1 = padding, first entry, end entry in the stream, ordinal in row)
     const int32_t *long_row;      // [n_long] row ids with nnz > LONG_T
     const int32_t *long_nch;      // [n_long] chunks of that row
     float *partials;              // [n_chunk_slots, D]  (slot = position in `chunks`)
@@ -312,8 +328,8 @@ struct SlicePlan {                // per XCD slice x: chunk blocks [cblk[x], cbl
 };
 
 struct SpmmArgs {
-    const int32_t *indices; const float *vals;
-    const int4 *rowinfo;          // short rows of the slices, padded per slice: (row | -1, first nnz, nnz count, 0)
+    const int2 *pk;               // packed (col, val bits) stream in plan order
+    const int4 *rowinfo;          // short rows of the slices, padded per slice: (row | -1, first entry in the stream, count, 0)
     LongPlan lp; SlicePlan sp;
     const void *X; void *Y;
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
@@ -341,7 +357,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
             //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
-            //  k_rows of the next step zeroes the stale one with plain stores)
+            //  k_bpr_loss of the next step zeroes the stale one with plain stores)
             i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
 #pragma unroll
             for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
@@ -459,7 +475,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         if (o < 0) return;
         const int64_t row = a.lp.long_row[o];
         const int nch = a.lp.long_nch[o];
-        Acc acc = row_gather<D, TI, SP>(a.indices, a.vals, ch.y, ch.z, src, lane, stage_lds[wid]);
+        Acc acc = row_gather<D, TI, SP>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
         if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
             if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc);
             return;
@@ -517,24 +533,70 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
             my_row = ri.x; my_s = ri.y; my_n = ri.z;
         }
         if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
-        int colr[NPW]; float valr[NPW]; int nr[NPW];
+        // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
+        // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
+        int off[NPW + 1];
+        off[0] = 0;
 #pragma unroll
-        for (int r = 0; r < NPW; r++) {                              // all index tiles in flight together
-            const int s0 = __builtin_amdgcn_readlane(my_s, r);
-            nr[r] = __builtin_amdgcn_readlane(my_n, r);
-            colr[r] = 0; valr[r] = 0.f;
-            if (lane < nr[r]) { colr[r] = a.indices[s0 + lane]; valr[r] = a.vals[s0 + lane]; }
+        for (int r = 0; r < NPW; r++) off[r + 1] = off[r] + __builtin_amdgcn_readlane(my_n, r);
+        const int tot = off[NPW];
+        const int64_t base = __builtin_amdgcn_readlane(my_s, 0);
+        int2 cvr[NPW];
+#pragma unroll
+        for (int it = 0; it < NPW; it++) {
+            cvr[it] = make_int2(0, 0);
+            if (it * 64 < tot) { const int e = it * 64 + lane; if (e < tot) cvr[it] = a.pk[base + e]; }
         }
-        int mycnt = 0, maxcnt = 0;
+        const int mylen = __shfl(my_n, g);
 #pragma unroll
-        for (int r = 0; r < NPW; r++) {
-            const int cnt = tile_stage<SP>(colr[r], valr[r], nr[r], src, lane, stage + r * ST);
-            if (cnt == 0 && lane == 0) stage[r * ST] = make_int2(0, 0);      // a valid column for the padding reads
-            if (g == r) mycnt = cnt;
-            maxcnt = max(maxcnt, cnt);
+        for (int it = 0; it < NPW; it++) {
+            if (it * 64 < tot) {
+                const int e = it * 64 + lane;
+                int r = 0;
+#pragma unroll
+                for (int k = 1; k < NPW; k++) r += (e >= off[k]) ? 1 : 0;
+                int o_r = 0;
+#pragma unroll
+                for (int k = 1; k < NPW; k++) o_r = (e >= off[k]) ? off[k] : o_r;
+                if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
+            }
+        }
+        if (lane < NPW && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
+        __builtin_amdgcn_wave_barrier();
+        int mycnt = mylen, maxcnt = 0;
+        if (SP) {
+            // keep only the neighbours whose row is flagged: every lane group compacts ITS row in place,
+            // LPR entries per round (one bitmap test instruction serves all the groups)
+            int maxlen = 0;
+#pragma unroll
+            for (int r = 0; r < NPW; r++) maxlen = max(maxlen, off[r + 1] - off[r]);
+            int2 *mine = stage + g * ST;
+            int cnt = 0;
+            for (int j0 = 0; j0 < maxlen; j0 += LPR) {
+                const int e = j0 + l;
+                const bool valid = e < mylen;
+                int2 cv = make_int2(0, 0);
+                if (valid) cv = mine[e];
+                const bool flag = valid && bit_set(src.bm, cv.x);
+                const unsigned long long m = __ballot(flag);
+                unsigned long long gm = m;
+                if constexpr (LPR < 64) gm = (m >> (g * LPR)) & ((1ull << LPR) - 1ull);
+                const int pos = cnt + __popcll(gm & ((1ull << l) - 1ull));
+                __builtin_amdgcn_wave_barrier();
+                if (flag) mine[pos] = cv;
+                cnt += __popcll(gm);
+            }
+            mycnt = cnt;
+            if (cnt == 0 && l == 0) mine[0] = make_int2(0, 0);
+            __builtin_amdgcn_wave_barrier();
+            maxcnt = mycnt;
+#pragma unroll
+            for (int o2 = LPR; o2 < 64; o2 <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o2));
+        } else {
+#pragma unroll
+            for (int r = 0; r < NPW; r++) maxcnt = max(maxcnt, off[r + 1] - off[r]);
         }
         maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
-        __builtin_amdgcn_wave_barrier();
         const int2 *mystage = stage + g * ST;
         const int last = max(mycnt - 1, 0);
         Acc acc = zerov<C>();
@@ -571,16 +633,15 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// BPR on the batch, ONE launch (a one-workgroup-per-triplet form kept a CU at 2 resident workgroups and
-// took 30 us: every slot row is its own small workgroup, and the triplet's third slot to finish does the
-// triplet's loss).
+// BPR on the batch, two launches (a one-workgroup-per-triplet form kept a CU at 2 resident workgroups and
+// took 30 us; split, every slot row is its own small workgroup).
 //
 // k_rows: one 256-thread workgroup per slot (3B slots: user, positive item, negative item of
 //   every triplet).  e = mean_k X_k[row]; the last layer X_K[row] = (A_hat X_{K-1})[row] is
 //   computed on the fly.  The 4 waves split the row's 64-entry tiles (positives are sampled
 //   proportionally to popularity: 1000-neighbour rows are common); a wave without work ends
 //   at once (s_barrier counts only surviving waves), so a typical slot costs one wave.
-//   Then triplet_loss (below) on the last of a triplet's three slots to arrive.
+//   k_bpr_loss: triplet_loss (below), one lane group per triplet.
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -599,7 +660,6 @@ struct BprArgs {
     float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
     int32_t terms_off, terms_stride;
     int32_t *err;
-    int32_t *tickets;     // [B_local] arrivals of a triplet's three slots (zero between steps)
 };
 
 __device__ __forceinline__ float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
@@ -621,24 +681,22 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
     return u < 0 || u >= a.n_users || p < 0 || (int64_t)p + a.n_users >= a.N || n < 0 || (int64_t)n + a.n_users >= a.N;
 }
 
-// Loss terms and the three gradient rows of ONE triplet by one wave.  Lane = column (mod 64): every
+// Loss terms and the three gradient rows of ONE triplet by one lane group.  Lane = column (mod 64): every
 // load, store and atomic wave-instruction covers min(D,64) contiguous elements -- 512 contiguous bytes
 // per 64-bit atomic instruction at d = 64.  (With 4 columns per lane the same atomics were 16 lanes x 8 B
 // at a 32-byte stride and cost 9 of a 13.7 us kernel.)  x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
 // r = |e_u|^2+|e_p|^2+|e_n|^2 ; gradient rows w.r.t. the propagated table -> fixed-point
 // atomics into G64 + row flags (single GPU / dense DP) or the exchange block (DP rows).
 template <int D>
-__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int lane) {
+__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
     constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
-    if (lane >= LPT) return;
-    const int l = lane;
     float u[CPL], p[CPL], n[CPL];
     float ps = 0.f, ns = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
 #pragma unroll
-    for (int j = 0; j < CPL; j++) {        // sc1 loads: the rows were written through by other workgroups
-        u[j] = __hip_atomic_load(a.ebuf + ((int64_t)0 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p[j] = __hip_atomic_load(a.ebuf + ((int64_t)1 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n[j] = __hip_atomic_load(a.ebuf + ((int64_t)2 * a.B_local + b) * D + j * LPT + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < CPL; j++) {
+        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
+        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
+        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
         ps += u[j] * p[j]; ns += u[j] * n[j]; ru += u[j] * u[j]; rp += p[j] * p[j]; rn += n[j] * n[j];
     }
     float rr = ru + rp + rn;
@@ -673,6 +731,20 @@ __device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int lane) 
     }
 }
 
+// (Doing this on the last of a triplet's three k_rows workgroups to arrive -- tickets, write-through rows --
+//  removed this launch but cost more than it saved: +9 us on k_rows, every workgroup pays the ticket's
+//  round trip before it can retire; measured 32.3 us fused vs 16.8 + 6.5 us split.)
+template <int D>
+__global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
+    constexpr int LPT = D < 64 ? D : 64, TPB = 256 / LPT;     // lanes per triplet, triplets per workgroup
+    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
+        a.stale_bitmap[i] = 0u;
+    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
+    if (b >= a.B_local) return;                 // whole lane groups leave together
+    triplet_loss<D>(a, b, l);
+}
+
 #ifndef BPR_BW
 #define BPR_BW 4
 #endif
@@ -686,7 +758,7 @@ __device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int6
     typedef Geo<D, TG, false> G;
     constexpr int C = G::CPL, LPR = G::LPR;
     GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
-    typename G::Acc xk = row_gather<D, TG, false>(a.indices, a.vals, s0, s1, src, lane, stage);
+    typename G::Acc xk = row_gather<D, TG, false>(CsrSrc{a.indices, a.vals}, s0, s1, src, lane, stage);
     if (nparts > 1) {
         if (lane < LPR) storev<C>(&part[q][lane * C], xk);
         __syncthreads();
@@ -696,41 +768,20 @@ __device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int6
             for (int w = 1; w < nparts; w++) xk += loadv<C>(&part[w][lane * C]);
         }
     }
-    // The slot's row is published WRITE-THROUGH (sc1), the wave drains and takes the triplet's ticket: the
-    // third of a triplet's three slots to arrive computes the triplet's loss and gradient rows right here
-    // (same hand-off as the long-row partials: sc1 stores -> vmcnt(0) -> agent-scope ticket; the last
-    // arriver acquires and reads with sc1 loads).  No separate loss kernel, no kernel boundary.
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
     if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
         const int64_t off = row * D + lane * C;
         typename G::Acc s = loadv<C>(a.X0 + off);
         for (int k = 1; k < a.K; k++) s += loadv<C>((const TI *)a.Xl[k] + off);
         s += xk;
         const float div = (float)(a.K + 1);
-        union { typename G::Acc v; unsigned long long q[C / 2]; } pk; pk.v = s / div;
-        gu64 *dst = (gu64 *)(a.ebuf + (int64_t)blockIdx.x * D + lane * C);
-#pragma unroll
-        for (int i = 0; i < C / 2; i++) __hip_atomic_store(dst + i, pk.q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        storev<C>(a.ebuf + (int64_t)blockIdx.x * D + lane * C, s / div);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int b = blockIdx.x % a.B_local;
-    int ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(a.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != 2) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(a.tickets + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next step
-    triplet_loss<D>(a, b, lane);
 }
 
 template <int D, typename TI>
 __global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
     __shared__ int2 stage_lds[BPR_BW][64];
     __shared__ __attribute__((aligned(32))) float part_lds[BPR_BW][D];
-    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
-    for (int64_t i = (int64_t)blockIdx.x * (64 * BPR_BW) + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * (64 * BPR_BW))
-        a.stale_bitmap[i] = 0u;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
@@ -879,6 +930,7 @@ extern "C" int lgcn_device_available(void) {
 // ---------------------------------------------------------------------------------
 struct lgcn_graph {
     const int32_t *indptr; const int32_t *indices; const float *vals; const int4 *rowinfo;
+    const int2 *pk;       // the planned rows' (col,val) pairs, packed, in plan order
     int64_t n_rows, nnz;
     int32_t d_max;
     LongPlan lp; SlicePlan sp;
@@ -906,6 +958,18 @@ __global__ void __launch_bounds__(256) k_index_range(const int32_t *indices, int
         b |= (c < 0 || c >= n_rows);
     }
     if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+// copy the planned rows' CSR segments into the packed stream: items = (first CSR entry, first stream entry, count, 0)
+__global__ void __launch_bounds__(256) k_pack_stream(const int4 *items, int64_t n_items, const int32_t *indices,
+                                                     const float *vals, int2 *pk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < n_items; i += nwaves) {
+        const int4 it = items[i];
+        for (int e = lane; e < it.z; e += 64)
+            pk[(int64_t)it.y + e] = make_int2(indices[(int64_t)it.x + e], __float_as_int(vals[(int64_t)it.x + e]));
+    }
 }
 
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
@@ -969,10 +1033,13 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         while (x <= XCDS) xs[x++] = n_order;
         xs[XCDS] = n_order;
     }
-    // ---- per slice: chunks of its long rows (padded to whole workgroups), then its short rows
-    std::vector<int32_t> long_row, long_nch, chunks, rowinfo;
+    // ---- per slice: chunks of its long rows (padded to whole workgroups), then its short rows; the
+    //      planned rows' entries go into the packed stream in exactly that order
+    std::vector<int32_t> long_row, long_nch, chunks, rowinfo, copyplan;
     SlicePlan sp{};
     rowinfo.reserve((size_t)n_order * 4 + 4 * SLICE_PAD * XCDS);
+    copyplan.reserve((size_t)n_order * 4);
+    int64_t n_pk = 0;
     for (int x = 0; x < XCDS; x++) {
         sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.rows[x] = (int32_t)(rowinfo.size() / 4);
         const size_t slice_begin = rowinfo.size();
@@ -981,11 +1048,15 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             const int32_t s0 = ip[(size_t)r], deg = ip[(size_t)r + 1] - s0;
             if (deg > LONG_T) {
                 const int nch = (deg + LONG_CH - 1) / LONG_CH;
+                const int32_t lb = (int32_t)n_pk;
                 for (int k = 0; k < nch; k++) {
-                    const int32_t c0 = s0 + k * LONG_CH, c1 = c0 + LONG_CH < s0 + deg ? c0 + LONG_CH : s0 + deg;
-                    const int32_t e[4] = {(int32_t)long_row.size(), c0, c1, k};
+                    const int32_t c0 = k * LONG_CH, c1 = c0 + LONG_CH < deg ? c0 + LONG_CH : deg;
+                    const int32_t e[4] = {(int32_t)long_row.size(), lb + c0, lb + c1, k};
                     chunks.insert(chunks.end(), e, e + 4);
                 }
+                const int32_t cp[4] = {s0, lb, deg, 0};
+                copyplan.insert(copyplan.end(), cp, cp + 4);
+                n_pk += deg;
                 long_row.push_back(r); long_nch.push_back(nch);
             } else {
                 const int32_t e[4] = {r, s0, deg, 0};
@@ -1000,6 +1071,13 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             std::stable_sort(tmp.begin(), tmp.end(), [](const std::array<int32_t, 4> &p, const std::array<int32_t, 4> &q) { return p[2] > q[2]; });
             for (size_t i = 0; i < n; i++) for (int k = 0; k < 4; k++) rowinfo[w0 + 4 * i + k] = tmp[i][k];
         }
+        // stream positions of the short rows, in their final order
+        for (size_t i = slice_begin; i < rowinfo.size(); i += 4) {
+            const int32_t cp[4] = {rowinfo[i + 1], (int32_t)n_pk, rowinfo[i + 2], 0};
+            if (cp[2] > 0) copyplan.insert(copyplan.end(), cp, cp + 4);
+            rowinfo[i + 1] = (int32_t)n_pk;
+            n_pk += rowinfo[i + 2];
+        }
         const int32_t pad[4] = {-1, 0, 0, 0};
         while ((chunks.size() / 4) % 4) chunks.insert(chunks.end(), pad, pad + 4);
         while ((rowinfo.size() / 4) % SLICE_PAD) rowinfo.insert(rowinfo.end(), pad, pad + 4);
@@ -1007,7 +1085,7 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     sp.cblk[XCDS] = (int32_t)(chunks.size() / 16); sp.rows[XCDS] = (int32_t)(rowinfo.size() / 4);
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
-    g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr;
+    g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr; g->pk = nullptr;
     g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
     g->owned = nullptr; g->lp = LongPlan{}; g->sp = sp;
     g->used = false; g->last_stream = nullptr; g->order_ev = nullptr;
@@ -1017,7 +1095,8 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t o_info = 0, o_chk = up(o_info + 16 * n_info), o_row = up(o_chk + 16 * n_slots),
                      o_nch = up(o_row + 4 * n_long), o_cnt = up(o_nch + 4 * n_long),
-                     o_par = up(o_cnt + 4 * n_long), total = o_par + n_slots * (size_t)d_max * 4 + 256;
+                     o_par = up(o_cnt + 4 * n_long), o_pk = up(o_par + n_slots * (size_t)d_max * 4),
+                     total = o_pk + 8 * (size_t)n_pk + 256;
         char *base = nullptr;
         if (hipMalloc((void **)&base, total) != hipSuccess) { (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
         g->owned = base;
@@ -1028,8 +1107,21 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             if (e1 == hipSuccess) e1 = hipMemcpy(base + o_row, long_row.data(), 4 * n_long, hipMemcpyHostToDevice);
             if (e1 == hipSuccess) e1 = hipMemcpy(base + o_nch, long_nch.data(), 4 * n_long, hipMemcpyHostToDevice);
         }
+        if (e1 == hipSuccess && !copyplan.empty()) {        // fill the packed stream on the device
+            int4 *items = nullptr;
+            e1 = hipMalloc((void **)&items, copyplan.size() * 4);
+            if (e1 == hipSuccess) e1 = hipMemcpy(items, copyplan.data(), copyplan.size() * 4, hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) {
+                const int64_t n_items = (int64_t)(copyplan.size() / 4), blocks = (n_items + 3) / 4;
+                hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, 0,
+                                   items, n_items, indices, vals, (int2 *)(base + o_pk));
+                e1 = hipDeviceSynchronize();
+            }
+            if (items) (void)hipFree(items);
+        }
         if (e1 != hipSuccess) { (void)hipFree(base); (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: plan upload failed"); return 10; }
         g->rowinfo = (const int4 *)(base + o_info);
+        g->pk = (const int2 *)(base + o_pk);
         if (n_long) {
             g->lp.chunks = (const int4 *)(base + o_chk);
             g->lp.long_row = (const int32_t *)(base + o_row); g->lp.long_nch = (const int32_t *)(base + o_nch);
@@ -1051,7 +1143,7 @@ extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
 
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.indices = g->indices; a.vals = g->vals; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp;
+    a.pk = g->pk; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp;
     return a;
 }
 
@@ -1127,7 +1219,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!cfg || !out) { lgcn_set_error("lgcn_ctx_create: null argument"); return 3; }
     const lgcn_train_config &c = *cfg;
     if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
-        !c.bitmap || !c.terms || !c.ebuf || !c.err || !c.tickets) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
+        !c.bitmap || !c.terms || !c.ebuf || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
     if (c.K > 1 && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
@@ -1185,16 +1277,18 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
     a.terms_off = atomics ? b_off : 0; a.terms_stride = B_global;
-    a.ebuf = c.ebuf; a.tickets = c.tickets;
+    a.ebuf = c.ebuf;
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
-        // two steps ago still has to be cleared (k_rows does it on the other ranks)
+        // two steps ago still has to be cleared (k_bpr_loss does it on the other ranks)
         HIP_OK(hipMemsetAsync(a.stale_bitmap, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
         return 0;
     }
     DISPATCH_D(c.d, {
         if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
         else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
+        const int tpb = 256 / (D < 64 ? D : 64);
+        hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
     });
     return 0;
 }

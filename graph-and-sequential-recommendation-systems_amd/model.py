@@ -206,7 +206,6 @@ class LightGCN(nn.Module):
         shard = (max_batch + dp_world - 1) // dp_world
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
-        st['tickets'] = torch.zeros(max_batch, dtype=torch.int32, device=dev)
         cfg = _lib.TrainConfig()
         cfg.graph = (st.get('graph_rs') or st['graph']).handle
         cfg.n_users, cfg.d, cfg.K = self.n_users, d, K
@@ -216,7 +215,6 @@ class LightGCN(nn.Module):
         cfg.bitmap, cfg.terms, cfg.contrib = st['bitmap'].data_ptr(), st['terms'].data_ptr(), st['contrib'].data_ptr()
         cfg.ebuf = st['ebuf'].data_ptr()
         cfg.err, cfg.max_batch = st['err'].data_ptr(), max_batch
-        cfg.tickets = st['tickets'].data_ptr()
         cfg.decay = float(self.config.get('decay', 1e-4))
         cfg.lr = float(self.config.get('lr', 1e-3))
         cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.999, 1e-8

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 4
+#define LGCN_ABI_VERSION 5
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -165,7 +165,6 @@ typedef struct {
     float *ebuf;                /* [3*max_batch*d] propagated rows of the batch slots */
     float *contrib;             /* [3*max_batch*d + 2*max_batch] (data-parallel exchange buffer) or NULL */
     int32_t *err;               /* [1] device error flag */
-    int32_t *tickets;           /* [max_batch] arrival counters of the triplets' slots */
     int32_t max_batch;
     /* hyper-parameters (utils.py:47-51, torch.optim.Adam defaults) */
     float decay;                /* config['decay'] */

@@ -77,9 +77,7 @@ def test_nine_million_rows_dim256(pkg, oracle):
     cfg.graph = g.handle; cfg.n_users, cfg.d, cfg.K, cfg.act_dtype = n_users, d, K, 0
     cfg.E0, cfg.adam_m, cfg.adam_v = E0.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
     cfg.act, cfg.G64, cfg.bitmap, cfg.terms, cfg.ebuf = act.data_ptr(), G64.data_ptr(), bitmap.data_ptr(), terms.data_ptr(), ebuf.data_ptr()
-    tickets = torch.zeros(B, dtype=torch.int32, device=DEV)
     cfg.contrib, cfg.err, cfg.max_batch, cfg.decay = None, errf.data_ptr(), B, 1e-4
-    cfg.tickets = tickets.data_ptr()
     cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = 1e-3, 0.9, 0.999, 1e-8, 1
     h = C.c_void_p()
     L.check(L.load().lgcn_ctx_create(C.byref(cfg), C.byref(h)), "ctx")

@@ -519,9 +519,9 @@ def test_spmm_row_length_boundaries(pkg, oracle, d):
     for order, xs in ((None, None), (rng.permutation(n).astype(np.int32), None), (rng.permutation(n).astype(np.int32), cut)):
         g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order, xcd_start=xs)
         got = g.spmm(_dev(X)).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=4e-6)          # rows of up to 1537 terms of |v x| <= 0.1: partial sums reach ~3
         again = g.spmm(_dev(2.0 * X)).cpu().numpy()    # other data through the same scratch: tickets were reset, no stale partial
-        np.testing.assert_allclose(again, 2.0 * ref, rtol=2e-5, atol=5e-6)      # 1537-term rows, doubled data
+        np.testing.assert_allclose(again, 2.0 * ref, rtol=2e-5, atol=8e-6)      # doubled data
         third = g.spmm(_dev(X)).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), third.view(np.uint32))
         if first is None:
@@ -744,7 +744,6 @@ def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, 
         cfg.act, cfg.G64, cfg.bitmap = st['act'].data_ptr(), st['G64'].data_ptr(), st['bitmap'].data_ptr()
         cfg.terms, cfg.ebuf, cfg.contrib = st['terms'].data_ptr(), st['ebuf'].data_ptr(), st['contrib'].data_ptr()
         cfg.err, cfg.max_batch, cfg.decay = st['err'].data_ptr(), B, float(g.meta["decay"])
-        cfg.tickets = st['tickets'].data_ptr()
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = float(g.meta["lr"]), 0.9, 0.999, 1e-8, 1
         h = C.c_void_p()
         L.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "ctx")
