@@ -341,7 +341,6 @@ struct SpmmArgs {
     const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
-    int packs;                    // packs a wave of the short-row path walks
 };
 
 enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
@@ -407,7 +406,7 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 // block of it): first the slice's long-row chunks, one per wave, then its short rows.
 //   M_SPARSE: X is Gs, read from the fixed-point table G64 for rows flagged in `bitmap`
 #ifndef SPMM_MIN_WAVES
-#define SPMM_MIN_WAVES 4      /* waves per SIMD the register allocation must allow (<= 128 VGPRs): a wave keeps up to
+#define SPMM_MIN_WAVES 6      /* waves per SIMD the register allocation must allow (<= 80 VGPRs): a wave keeps up to
                                  NPW x 8 row gathers in flight, so residency is not what hides the latency */
 #endif
 #ifndef SPMM_U
@@ -433,15 +432,8 @@ __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycn
     for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u], src.div);
 }
 
-// packs a wave of the short-row path walks (software-pipelined) and the blocks a slice then needs
-#ifndef SPMM_ROWS_PER_WAVE
-#define SPMM_ROWS_PER_WAVE 16
-#endif
-static inline int packs_per_wave(int npw) { const int p = SPMM_ROWS_PER_WAVE / npw; return p < 1 ? 1 : p; }
-static inline unsigned slice_blocks(const SlicePlan &sp, int x, int npw, int packs) {
-    const int npk = (sp.rows[x + 1] - sp.rows[x]) / npw, W = (npk + packs - 1) / packs;
-    return (unsigned)((sp.cblk[x + 1] - sp.cblk[x]) + (W + 3) / 4);
-}
+// rows per workgroup of a kernel variant: 4 waves x PACKS packs x NPW rows
+template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= 4 ? 1 : 4 / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
 
 template <int D, typename TI, typename TO, int MODE>
 __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
@@ -450,6 +442,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     typedef typename G::Acc Acc;
     typedef Raw<TI, SP> R;
     constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
+    constexpr int PACKS = PackGeo<NPW>::PACKS, RPW = PackGeo<NPW>::RPW, RPB = PackGeo<NPW>::RPB;
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
     constexpr int U = SP ? 4 : SPMM_U;
     __shared__ int2 stage_lds[4][NPW * ST];
@@ -468,8 +461,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     else {        // slices as contiguous block ranges (placement-independent either way: speed only)
         x = 0; j = blockIdx.x;
         while (x < XCDS - 1) {
-            const int npk_ = (a.sp.rows[x + 1] - a.sp.rows[x]) / NPW, W_ = (npk_ + a.packs - 1) / a.packs;
-            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (W_ + 3) / 4;
+            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB;
             if (j < nb) break;
             j -= nb; x++;
         }
@@ -520,83 +512,56 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot);
         return;
     }
-    // ---- short rows (<= 64 non-zeros): a pack of NPW rows at a time, ONE ROW PER LANE GROUP: every group
-    //      walks its own row U gathers deep -- NPW x U row gathers in flight per wave (32 at d = 64 fp32, 64
-    //      with a bf16 table), no cross-group reduction, no divergence (the trip count is the pack's longest
-    //      row; shorter rows pad with zero-weight re-reads of their last entry, and the plan sorts windows of
-    //      rows by length so there is little to pad).  A row is summed in CSR order by one accumulator
-    //      chain -- the reference's own order.
-    //      A wave takes a.packs packs, software-pipelined: while pack s gathers, the index tiles of pack
-    //      s+1 and the plan entry of pack s+2 are already in flight, so after the first pack the only
-    //      exposed round trip per pack is the gather itself.  The slice's waves take the packs STRIDED
-    //      (wave w: packs w, w+W, w+2W, ...): at any moment the XCD works on one contiguous part of its
-    //      slice, and every wave gets packs from all over the length-sorted windows (even work per wave).
-    const int npk = (a.sp.rows[x + 1] - a.sp.rows[x]) / NPW;        // packs of the slice (padding packs included)
-    const int W = (npk + a.packs - 1) / a.packs;                    // waves of the slice
-    const int w = (j - ncb) * 4 + wid;
-    if (w >= W) return;
+    // ---- short rows (<= 64 non-zeros): a pack of NPW rows at a time, ONE ROW PER LANE GROUP.  All
+    //      index tiles of the pack are loaded back to back, then every group walks its own row U
+    //      gathers deep: NPW x U row gathers in flight per wave (32 at d = 64 fp32, 64 with a bf16
+    //      table) instead of one row's worth, no cross-group reduction, no divergence (the trip
+    //      count is the pack's longest row; shorter rows pad with zero-weight re-reads of their
+    //      last entry, and the plan sorts windows of rows by length so there is little to pad).
+    //      A row is summed in CSR order by one accumulator chain -- the reference's own order.
+    const int t = j - ncb;
+    if (t >= (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB) return;
     const int g = lane / LPR, l = lane % LPR;
     int2 *stage = stage_lds[wid];
-    const int4 *ri_base = a.rowinfo + a.sp.rows[x];
-    // plan entries of the wave's first two packs; index tiles of the first
-    int4 ri_cur = make_int4(-1, 0, 0, 0), ri_nxt = make_int4(-1, 0, 0, 0);
-    if (lane < NPW) {
-        ri_cur = ri_base[(int64_t)w * NPW + lane];
-        if (W + w < npk && a.packs > 1) ri_nxt = ri_base[(int64_t)(W + w) * NPW + lane];
-    }
-    int2 cvr[NPW];
-    {
-        int tot0 = 0;
-#pragma unroll
-        for (int r = 0; r < NPW; r++) tot0 += __builtin_amdgcn_readlane(ri_cur.z, r);
-        const int64_t base0 = __builtin_amdgcn_readlane(ri_cur.y, 0);
-#pragma unroll
-        for (int it = 0; it < NPW; it++) {
-            cvr[it] = make_int2(0, 0);
-            if (it * 64 < tot0) { const int e = it * 64 + lane; if (e < tot0) cvr[it] = a.pk[base0 + e]; }
-        }
-    }
 #pragma unroll 1
-    for (int sI = 0; sI < a.packs; sI++) {
-        if (sI * W + w >= npk) break;
-        const int my_row = ri_cur.x, my_n = ri_cur.z;
+    for (int pk = 0; pk < PACKS; pk++) {
+        const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)t * RPB + (wid * PACKS + pk) * NPW;
+        // lane r < NPW fetches (row id, first nnz, count) of row r with ONE 16-byte load from the plan
+        int my_row = -1, my_s = 0, my_n = 0;
+        if (lane < NPW) {
+            const int4 ri = a.rowinfo[pos0 + lane];
+            my_row = ri.x; my_s = ri.y; my_n = ri.z;
+        }
+        if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
         // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
-        // off[r] <= e < off[r+1]
+        // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
         int off[NPW + 1];
         off[0] = 0;
 #pragma unroll
         for (int r = 0; r < NPW; r++) off[r + 1] = off[r] + __builtin_amdgcn_readlane(my_n, r);
         const int tot = off[NPW];
+        const int64_t base = __builtin_amdgcn_readlane(my_s, 0);
+        int2 cvr[NPW];
+#pragma unroll
+        for (int it = 0; it < NPW; it++) {
+            cvr[it] = make_int2(0, 0);
+            if (it * 64 < tot) { const int e = it * 64 + lane; if (e < tot) cvr[it] = a.pk[base + e]; }
+        }
         const int mylen = __shfl(my_n, g);
 #pragma unroll
         for (int it = 0; it < NPW; it++) {
             if (it * 64 < tot) {
                 const int e = it * 64 + lane;
-                int r = 0, o_r = 0;
+                int r = 0;
 #pragma unroll
-                for (int k = 1; k < NPW; k++) { r += (e >= off[k]) ? 1 : 0; o_r = (e >= off[k]) ? off[k] : o_r; }
+                for (int k = 1; k < NPW; k++) r += (e >= off[k]) ? 1 : 0;
+                int o_r = 0;
+#pragma unroll
+                for (int k = 1; k < NPW; k++) o_r = (e >= off[k]) ? off[k] : o_r;
                 if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
             }
         }
         if (lane < NPW && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
-        // ---- prefetch: index tiles of the next pack (its plan entry arrived a pack ago), plan entry of the one after
-        {
-            int totn = 0;
-#pragma unroll
-            for (int r = 0; r < NPW; r++) totn += __builtin_amdgcn_readlane(ri_nxt.z, r);
-            const int64_t basen = __builtin_amdgcn_readlane(ri_nxt.y, 0);
-#pragma unroll
-            for (int it = 0; it < NPW; it++) {
-                cvr[it] = make_int2(0, 0);
-                if (it * 64 < totn) { const int e = it * 64 + lane; if (e < totn) cvr[it] = a.pk[basen + e]; }
-            }
-        }
-        ri_cur = ri_nxt;
-        ri_nxt = make_int4(-1, 0, 0, 0);
-        {
-            const int64_t p2 = (int64_t)(sI + 2) * W + w;
-            if (sI + 2 < a.packs && p2 < npk && lane < NPW) ri_nxt = ri_base[p2 * NPW + lane];
-        }
         __builtin_amdgcn_wave_barrier();
         int mycnt = mylen, maxcnt = 0;
         if (SP) {
@@ -644,7 +609,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
         if (maxcnt - u0 > 0) pack_batch<D, TI, SP, 1>(mystage, u0, mycnt, last, src, l, acc);
         const int mrow = __shfl(my_row, g);
         if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
-        __builtin_amdgcn_wave_barrier();
+        if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -904,13 +869,12 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // launch helpers
 // ---------------------------------------------------------------------------------
 template <int D, typename TI, typename TO, int MODE>
-static void launch_spmm_t(SpmmArgs a, hipStream_t st) {
-    constexpr int NPW = Geo<D, TI, (MODE & M_SPARSE) != 0>::NPW;
-    static_assert(SLICE_PAD % NPW == 0, "slice padding must hold whole packs of every variant");
-    a.packs = packs_per_wave(NPW);
+static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
+    constexpr int RPB = PackGeo<Geo<D, TI, (MODE & M_SPARSE) != 0>::NPW>::RPB;
+    static_assert(SLICE_PAD % RPB == 0, "slice padding must hold whole workgroups of every variant");
     unsigned grid = 0, widest = 0;
     for (int x = 0; x < XCDS; x++) {
-        const unsigned nb = slice_blocks(a.sp, x, NPW, a.packs);
+        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB);
         grid += nb; widest = nb > widest ? nb : widest;
     }
     if (a.remap) grid = widest * XCDS;
@@ -1053,8 +1017,9 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         bool ok = xs[0] == 0 && xs[XCDS] == n_order;
         for (int x = 0; x < XCDS; x++) ok = ok && xs[x] <= xs[x + 1];
         if (!ok) { lgcn_set_error("lgcn_graph_create: xcd_start must be 9 non-decreasing positions from 0 to n_order"); return 3; }
-    } else {                     // balance the work: non-zeros plus a per-row constant
-        double total = 4.0 * (double)n_order;
+    } else {                     // balance the work: non-zeros plus a per-row constant (see reorder.py _row_cost)
+        const double ROW_COST = 16.0;          // a row costs about as much as 16 of its non-zeros (plan entry, index tile, epilogue)
+        double total = ROW_COST * (double)n_order;
         for (int64_t p = 0; p < n_order; p++) {
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
             total += (double)(ip[(size_t)r + 1] - ip[(size_t)r]);
@@ -1063,7 +1028,7 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
         xs[0] = 0;
         for (int64_t p = 0; p < n_order && x < XCDS; p++) {
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
-            acc += (double)(ip[(size_t)r + 1] - ip[(size_t)r]) + 4.0;
+            acc += (double)(ip[(size_t)r + 1] - ip[(size_t)r]) + ROW_COST;
             while (x < XCDS && acc >= total * x / XCDS) xs[x++] = p + 1;
         }
         while (x <= XCDS) xs[x++] = n_order;

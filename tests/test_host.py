@@ -248,7 +248,7 @@ def test_row_orders_are_permutations(pkg, tiny, lastfm, tmp_path):
         for method in ('rcm', 'cocluster', 'xcd'):
             o, xs = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)
             assert o.dtype == np.int32 and np.array_equal(np.sort(o), np.arange(N)), method
-            assert os.path.exists(os.path.join(ds.path, f"s_row_order_{method}.npz"))
+            assert any(f.startswith(f"s_row_order_{method}") for f in os.listdir(ds.path))
             o2, xs2 = pkg.reorder.row_order(method, ds, adj, cache_dir=ds.path)                    # cached
             assert np.array_equal(o, o2)
             if method == 'xcd':      # the 8 XCD slices: a monotone cut of the order, balanced by non-zeros
