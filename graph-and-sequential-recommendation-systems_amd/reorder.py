@@ -71,10 +71,10 @@ def _fiedler(sub, seed=0):
 
 
 def _row_cost():
-    """Work of a row in units of one non-zero: cost = nnz + ROW_COST.  The per-row part (plan entry, index
-    tile, epilogue) is what a short row mostly costs; slices balanced by non-zeros alone differed by 1.9x
-    in their number of short rows on Gowalla, and the launch waits for the slowest XCD."""
-    return float(os.environ.get("LGCN_ROW_COST", "16"))
+    """Work of a row in units of one non-zero: cost = nnz + ROW_COST.  Measured on Gowalla (slices balanced
+    by non-zeros alone differ 1.9x in their number of short rows): 0 / 8 / 16 give the same launch time,
+    32 and 64 are slower, and on the heavy-tailed synthetic shapes 16 costs 15-20 %: the default is 0."""
+    return float(os.environ.get("LGCN_ROW_COST", "0"))
 
 
 def xcd_order(R, n_users, m_items, parts=8, leaf_nnz=4096, seed=0):

@@ -4,7 +4,7 @@ prescribes: FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS each in its own pass) into pe
 bytes of the dominant kernel:  traffic = 2 * FETCH_SIZE (gfx950 half-count of wide reads) + WRITE_SIZE,
 KiB units, cross-checked with TCC_MISS * 128 B.
 
-    python profiles/pmc_traffic.py <dir with pmc_fetch_<dt>/ pmc_write_<dt>/ pmc_l2_<dt>/> [--write workload]
+    python profiles/pmc_traffic.py <dir with pmc_fetch_<dt>/ pmc_write_<dt>/ pmc_l2_<dt>/> [--write workload [--out file.json]]
 
 --write stores the result in profiles/hbm_traffic.json keyed by workload:dtype:k_spmm together with the
 source hash of the library it was measured on; bench.py reports it only while that hash matches."""
@@ -31,6 +31,7 @@ def counters(d):
 def main():
     root = sys.argv[1]
     write = sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--write" else None
+    out_path = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--out" else os.path.join(REPO, "profiles", "hbm_traffic.json")
     out = {}
     for dt in ("fp32", "bf16"):
         vals = {}
@@ -51,7 +52,7 @@ def main():
         out[dt] = traffic
     if write:
         pkg = importlib.import_module("graph-and-sequential-recommendation-systems_amd")
-        path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        path = out_path
         try:
             db = json.load(open(path))
         except Exception:
