@@ -210,7 +210,7 @@ def main():
     s = 4 if a.act_dtype == "fp32" else 2
     adt = 0 if a.act_dtype == "fp32" else 1
     L = pkg._lib
-    lib_hash = pkg.build.source_hash()
+    lib_hash = pkg.build.kernel_hash()
 
     def spmm_kernel_time(reps):
         """dominant kernel (dense CSR-SpMM layer) timed live with HIP events on the launch stream"""
@@ -377,7 +377,8 @@ def main():
                                       f"model.py:201-231 + utils.py:53-64 (oracle/torch_eager.py), {dt_te:.1f} s; the "
                                       "reference itself measured 1.45-2.22 steps/s on 8 cores (BASELINE.md)"}}
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        print("\n" + json.dumps(out), flush=True)        # on a line of its own whatever a library wrote to stdout before
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

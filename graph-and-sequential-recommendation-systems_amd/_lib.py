@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -28,7 +28,7 @@ class TrainConfig(C.Structure):
         ("err", _vp), ("max_batch", C.c_int32),
         ("decay", C.c_float),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-        ("xcd_remap", C.c_int32), ("reserved", C.c_int32),
+        ("xcd_remap", C.c_int32), ("dense_last", C.c_int32),
     ]
 
 

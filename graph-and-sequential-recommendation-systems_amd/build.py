@@ -42,6 +42,13 @@ def source_hash(extra_flags=()):
     return h.hexdigest()
 
 
+def kernel_hash():
+    """Hash of the source of the training kernels only (csrc/lgcn_device.hip): what a PMC measurement of
+    k_spmm stays valid for."""
+    with open(os.path.join(PKG_DIR, "csrc", "lgcn_device.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def _stamp_path(lib=None):
     return (lib or LIB_PATH) + ".srchash"
 

@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
 // computer() (model.py:221-222) as one streaming pass.  The K-th layer itself runs through k_spmm
 // like the others, so evaluation gets the split long rows too.
 struct MeanArgs {
-    const float *X0; const void *Xl[LGCN_MAX_LAYERS]; int K;
+    const float *X0; const void *Xl[LGCN_MAX_LAYERS + 1]; int K;
     float *out; int64_t n4;      // number of 4-element pieces
 };
 
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
-    const float *X0; const void *Xl[LGCN_MAX_LAYERS]; int K;
+    const float *X0; const void *Xl[LGCN_MAX_LAYERS + 1]; int K;
     int32_t n_users; int64_t N;
     const int32_t *users; const int32_t *pos; const int32_t *neg;   // already offset to the local shard
     int32_t B_local;      // triplets handled by this launch
@@ -660,6 +660,7 @@ struct BprArgs {
     float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
     int32_t terms_off, terms_stride;
     int32_t *err;
+    int32_t dense_last;   // X_K exists densely (Xl[K]): the slot rows are read, not gathered
 };
 
 __device__ __forceinline__ float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
@@ -794,6 +795,25 @@ __global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
     const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
     if (a.K == 1) rows_body<D, float, TI>(a, a.X0, row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
     else rows_body<D, TI, TI>(a, a.Xl[a.K - 1], row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
+}
+
+// Slot rows when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row
+// reads.  On graphs whose positives concentrate on hub items (a popularity-weighted mean item degree in the
+// thousands: the synthetic Yelp / Amazon shapes) the slots together hold several times the graph's non-zeros
+// -- one more dense SpMM is then far cheaper than k_rows' per-slot gathers (236 -> ~50 us at B = 8192).
+template <int D, typename TI>
+__global__ void __launch_bounds__(256) k_rows_dense(BprArgs a) {
+    constexpr int LPR = D / 4, SPB = 256 / LPR;
+    const int64_t s = (int64_t)blockIdx.x * SPB + threadIdx.x / LPR;
+    const int l = threadIdx.x % LPR;
+    if (s >= (int64_t)3 * a.B_local) return;
+    const int c = (int)(s / a.B_local), b = (int)(s % a.B_local);
+    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
+    if (triplet_bad(a, b)) { if (l == 0) atomicExch(a.err, 1); row = 0; }
+    const int64_t off = row * D + l * 4;
+    f32x4 acc = load4(a.X0 + off);
+    for (int k = 1; k <= a.K; k++) acc += load4((const TI *)a.Xl[k] + off);
+    store4(a.ebuf + s * D + l * 4, acc / (float)(a.K + 1));
 }
 
 // slot -> destination row of the global batch (-1: the slot's triplet has a bad id)
@@ -1213,7 +1233,8 @@ struct lgcn_ctx {
     int64_t N;
     int64_t bm_words;             // words per bitmap; cfg.bitmap holds two, used alternately
     int flip;
-    void *act[LGCN_MAX_LAYERS];   // act[k] = X_k storage for k = 1..K-1 (also reused for H)
+    void *act[LGCN_MAX_LAYERS + 1];   // act[k] = X_k storage for k = 1..K-1 (K with dense_last; also reused for H)
+    int fwd_layers;               // dense forward layers per step: K-1, or K with dense_last
 };
 
 extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
@@ -1222,7 +1243,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
         !c.bitmap || !c.terms || !c.ebuf || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
-    if (c.K > 1 && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
+    if ((c.K > 1 || c.dense_last) && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
     if (check_dtype(c.act_dtype)) return 3;
     if (c.n_users <= 0 || c.n_users >= c.graph->n_rows || c.max_batch <= 0) { lgcn_set_error("lgcn_ctx_create: bad sizes"); return 3; }
@@ -1232,8 +1253,9 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     x->c = c; x->step = 0; x->N = c.graph->n_rows;
     x->bm_words = (x->N + 31) / 32; x->flip = 0;
     const size_t stride = (size_t)x->N * c.d * esize(c.act_dtype);
-    for (int k = 0; k < LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
-    for (int k = 1; k < c.K; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
+    for (int k = 0; k <= LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
+    x->fwd_layers = c.dense_last ? c.K : c.K - 1;
+    for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     *out = x;
     return 0;
 }
@@ -1254,7 +1276,7 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     const void *prev = c.E0; int prev_dt = LGCN_F32;
-    for (int k = 1; k < c.K; k++) {
+    for (int k = 1; k <= x->fwd_layers; k++) {
         SpmmArgs a = base_spmm(x);
         a.X = prev; a.Y = x->act[k];
         int rc = launch_spmm<0>(a, c.d, prev_dt, c.act_dtype, st);
@@ -1269,7 +1291,8 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     const lgcn_train_config &c = x->c;
     BprArgs a{};
     a.indptr = c.graph->indptr; a.indices = c.graph->indices; a.vals = c.graph->vals; a.X0 = c.E0; a.K = c.K;
-    for (int k = 1; k < c.K; k++) a.Xl[k] = x->act[k];
+    for (int k = 1; k <= x->fwd_layers; k++) a.Xl[k] = x->act[k];
+    a.dense_last = c.dense_last;
     a.n_users = c.n_users; a.N = x->N;
     a.users = users + b_off; a.pos = pos + b_off; a.neg = neg + b_off;
     a.B_local = B_local; a.shard = shard;
@@ -1286,7 +1309,12 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
         return 0;
     }
     DISPATCH_D(c.d, {
-        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
+        if (c.dense_last) {
+            const unsigned gd = (unsigned)(((int64_t)3 * B_local + 256 / (D / 4) - 1) / (256 / (D / 4)));
+            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_rows_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
+        }
+        else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
         else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
         const int tpb = 256 / (D < 64 ? D : 64);
         hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
@@ -1461,7 +1489,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     if ((rc = graph_acquire(c.graph, st))) return rc;
     switch (phase) {
     case LGCN_RS_FWD: {                               // X_k[owned] = (A X_{k-1})[owned], k = 1..K-1
-        if (k < 1 || k >= c.K) { lgcn_set_error("lgcn_rs_phase: forward layer out of range"); return 3; }
+        if (k < 1 || k > x->fwd_layers) { lgcn_set_error("lgcn_rs_phase: forward layer out of range"); return 3; }
         SpmmArgs a = base_spmm(x);
         a.X = k == 1 ? (const void *)c.E0 : x->act[k - 1]; a.Y = x->act[k];
         rc = launch_spmm<0>(a, c.d, k == 1 ? LGCN_F32 : c.act_dtype, c.act_dtype, st);
@@ -1504,7 +1532,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
 extern "C" int lgcn_rs_buffer(const lgcn_ctx *x, int32_t phase, int32_t k, void **buf, int32_t *dtype) {
     if (!x || !buf || !dtype) { lgcn_set_error("lgcn_rs_buffer: null argument"); return 3; }
     const lgcn_train_config &c = x->c;
-    if (phase == LGCN_RS_FWD && k >= 1 && k < c.K) { *buf = x->act[k]; *dtype = c.act_dtype; return 0; }
+    if (phase == LGCN_RS_FWD && k >= 1 && k <= x->fwd_layers) { *buf = x->act[k]; *dtype = c.act_dtype; return 0; }
     if (phase == LGCN_RS_BWD && k > 1 && k <= c.K) { *buf = bwd_buffer(x, k); *dtype = c.act_dtype; return 0; }
     if (phase == LGCN_RS_BWD && k == 1) { *buf = c.E0; *dtype = LGCN_F32; return 0; }
     lgcn_set_error("lgcn_rs_buffer: this phase exchanges nothing");
@@ -1551,7 +1579,7 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
             const int32_t K = x->c.K, d = x->c.d;
             const int32_t *u = users + t, *p = pos + t, *n = neg + t;
             void *buf; int32_t dt;
-            for (int k = 1; k < K; k++) {
+            for (int k = 1; k <= x->fwd_layers; k++) {
                 if ((rc = lgcn_rs_phase(x, LGCN_RS_FWD, k, u, p, n, b, world, rank, nullptr, nullptr, stream))) return rc;
                 if ((rc = lgcn_rs_buffer(x, LGCN_RS_FWD, k, &buf, &dt))) return rc;
                 if ((rc = rs_exchange(api, dp, buf, dt, d, row_ranges, st))) return rc;

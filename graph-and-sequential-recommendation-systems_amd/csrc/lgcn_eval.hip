@@ -49,7 +49,9 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
     constexpr int LPT = 32 * D * 4 / 16 / 256;          // 16-byte pieces per thread per item tile
     static_assert(LPT >= 1, "tile smaller than the workgroup");
     __shared__ __attribute__((aligned(16))) float tile_lds[2][32 * RS];
-    __shared__ float list_s[256][EVAL_KMAX + 1];       // +1: odd stride, lanes scan their lists conflict-free
+    // per-lane candidate lists: always EVAL_KMAX slots (slots >= K hold +inf: never the minimum, never output),
+    // 16-byte aligned rows so the minimum scan is 8 independent ds_read_b128
+    __shared__ __attribute__((aligned(16))) float list_s[256][EVAL_KMAX + 4];
     __shared__ int32_t list_i[256][EVAL_KMAX + 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
         if (tp < tend) nid = a.train_idx[tp];
         if (tp + 1 < tend) nnid = a.train_idx[tp + 1];
     }
-    for (int k = 0; k < K; k++) { list_s[tid][k] = EVAL_NEG_INF; list_i[tid][k] = -1; }
+    for (int k = 0; k < EVAL_KMAX; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = -1; }
     float thr = EVAL_NEG_INF;      // the lane's K-th best so far
     int pmin = 0;                  // where it sits in the list
 
@@ -134,8 +136,13 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
             if (base + row >= a.m_items) sc = EVAL_NEG_INF;             // past the table
             if (sc > thr) {
                 list_s[tid][pmin] = sc; list_i[tid][pmin] = base + row;
-                float m = list_s[tid][0]; int pm = 0;
-                for (int k = 1; k < K; k++) { const float v = list_s[tid][k]; if (v < m) { m = v; pm = k; } }
+                // new minimum: all slots read at once (no dependent LDS round trips), then a register scan
+                f32x4 q[EVAL_KMAX / 4];
+#pragma unroll
+                for (int k4 = 0; k4 < EVAL_KMAX / 4; k4++) q[k4] = *reinterpret_cast<const f32x4 *>(&list_s[tid][4 * k4]);
+                float m = q[0].x; int pm = 0;
+#pragma unroll
+                for (int k = 1; k < EVAL_KMAX; k++) { const float v = q[k / 4][k % 4]; if (v < m) { m = v; pm = k; } }
                 thr = m; pmin = pm;
             }
         }

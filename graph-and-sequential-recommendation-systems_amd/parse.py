@@ -66,6 +66,9 @@ def build_parser():
                    help='NEW: processing order of graph rows in the SpMM kernels (L2 locality; results unchanged)')
     p.add_argument('--prefetch_epoch', type=int, default=0,
                    help='NEW: 1 = sample/shuffle/upload epoch e+1 while epoch e runs on the GPU')
+    p.add_argument('--dense_last', type=str, default='auto', choices=['auto', '0', '1'],
+                   help='NEW: last forward layer on the batch rows only (0), densely (1), or whichever is cheaper for '
+                        'this graph and batch size (auto)')
     p.add_argument('--gpu_sampler', type=int, default=1,
                    help='NEW: 1 = the cpp-mode BPR sampler runs on the GPU (same rand() stream, same rows); 0 = on the host')
     p.add_argument('--eval_fused', type=int, default=1,

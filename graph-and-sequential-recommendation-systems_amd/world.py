@@ -101,6 +101,7 @@ def configure(argv=None):
     config['prefetch_epoch'] = args.prefetch_epoch
     config['eval_fused'] = args.eval_fused
     config['gpu_sampler'] = args.gpu_sampler
+    config['dense_last'] = args.dense_last
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 5
+#define LGCN_ABI_VERSION 6
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -158,7 +158,7 @@ typedef struct {
     float *adam_m;
     float *adam_v;
     /* workspace, caller-allocated, zero-initialised before the first step */
-    void *act;                  /* max(1,K-1) * N*d elements of act_dtype */
+    void *act;                  /* max(1, dense_last ? K : K-1) * N*d elements of act_dtype */
     int64_t *G64;               /* [N,d] fixed-point (2^50) accumulator of the sparse-row gradient */
     uint32_t *bitmap;           /* [2*ceil(N/32)] rows of G64 that are non-zero (two, used alternately) */
     float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
@@ -170,7 +170,9 @@ typedef struct {
     float decay;                /* config['decay'] */
     double lr, beta1, beta2, eps;
     int32_t xcd_remap;          /* 1: contiguous row ranges per XCD */
-    int32_t reserved;
+    int32_t dense_last;         /* 1: propagate the LAST layer densely too and read the batch rows from it (needs K
+                                   activation buffers); 0: compute it only on the 3B batch rows (K-1 buffers).  Pays
+                                   when the batch rows together hold more non-zeros than the graph (hub-heavy data) */
 } lgcn_train_config;
 
 int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out);

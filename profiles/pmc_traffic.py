@@ -58,7 +58,7 @@ def main():
         except Exception:
             db = {}
         for dt, t in out.items():
-            db[f"{write}:{dt}:k_spmm"] = {"bytes": t, "lib_hash": pkg.build.source_hash(),
+            db[f"{write}:{dt}:k_spmm"] = {"bytes": t, "lib_hash": pkg.build.kernel_hash(),
                                           "source": f"rocprofv3 --pmc passes under {os.path.relpath(root, REPO)} (2*FETCH_SIZE + WRITE_SIZE)"}
         json.dump(db, open(path, "w"), indent=1)
         print("wrote", path)

@@ -825,3 +825,29 @@ def test_gpu_sampler_bit_exact(pkg, oracle, tiny, tmp_path):
     for prefix in ("978d20809083cea5", "dcfb3021bcc6755a"):
         Sg = S.sample_negative_device(gds.n_users, gds.m_items, gds.trainDataSize, gds.pos_csr(), DEV).cpu().numpy()
         assert Sg.shape == (806166, 3) and hashlib.sha256(Sg.tobytes()).hexdigest().startswith(prefix)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_dense_last_layer_option_vs_oracle(pkg, oracle, tiny, tmp_path, K):
+    """cfg.dense_last = 1 (last layer propagated densely, batch rows read from it -- what 'auto' picks on
+    hub-heavy graphs): three fused steps vs the oracle, and against the default path on the same inputs
+    (same result up to fp32 summation order)."""
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(20 + K))
+    batches = [(rng.integers(0, g.n_users, b), rng.integers(0, g.m_items, b), rng.integers(0, g.m_items, b)) for b in (64, 64, 9)]
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    tables = {}
+    for mode in ("1", "0"):
+        ds, m = _make_model(pkg, g, tmp_path, K=K)
+        m.config['dense_last'] = mode
+        tr = oracle.Trainer(g.n_users, *A, g.e0(), K, g.meta["decay"], g.meta["lr"])
+        bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+        for (u, p, n) in batches:
+            l_ref = tr.stageOne(u, p, n)
+            l_got = bpr.stageOne(_dev(u), _dev(p), _dev(n))
+            assert abs(l_got - l_ref) < 3e-6, (mode, l_got, l_ref)
+            np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=3e-6)
+        assert m._dev['dense_last'] == (mode == "1")
+        assert int(m._dev['G64'].abs().sum()) == 0
+        tables[mode] = m._table.cpu().numpy().copy()
+    np.testing.assert_allclose(tables["1"], tables["0"], rtol=0, atol=2e-6)
