@@ -745,10 +745,12 @@ def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, 
         cfg.terms, cfg.ebuf, cfg.contrib = st['terms'].data_ptr(), st['ebuf'].data_ptr(), st['contrib'].data_ptr()
         cfg.err, cfg.max_batch, cfg.decay = st['err'].data_ptr(), B, float(g.meta["decay"])
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = float(g.meta["lr"]), 0.9, 0.999, 1e-8, 1
+        cfg.dense_last = int(st['dense_last'])               # same last-layer mode as the reference run
         h = C.c_void_p()
         L.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "ctx")
         ctxs.append(h)
     K = g.K
+    fwd_layers = K if st['dense_last'] else K - 1
     FWD, BPR, SCATTER, BWD, FINISH = 0, 1, 2, 3, 4
     stream = L.current_stream()
     for i, (u, p, n) in enumerate(batches):
@@ -758,7 +760,7 @@ def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, 
             L.check(lib.lgcn_rs_phase(ctxs[r], ph, k, L.tp(u), L.tp(p), L.tp(n), b, world, r,
                                       L.tp(gathered) if gathered is not None else None,
                                       L.tp(loss) if loss is not None else None, stream), f"phase {ph} {k}")
-        for k in range(1, K):
+        for k in range(1, fwd_layers + 1):
             for r in range(world):
                 phase(r, FWD, k)
         nblk = pkg.parallel.block_numel(b, world, g.d)
