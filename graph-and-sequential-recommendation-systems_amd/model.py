@@ -198,7 +198,7 @@ class LightGCN(nn.Module):
         if 'adam_m' not in st:
             st['adam_m'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
             st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
-        dense_last = self._dense_last(max_batch)
+        dense_last = self._dense_last(int(self.config.get('bpr_batch_size', max_batch)))     # the configured batch, not this context's capacity
         st['act'] = torch.zeros(max(1, K if dense_last else K - 1), N, d, dtype=tdt, device=dev)
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
         st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
