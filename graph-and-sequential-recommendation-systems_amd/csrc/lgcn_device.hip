@@ -315,14 +315,14 @@ row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int l
 // load holds its address/return path as long as a 64-lane 1-KiB row gather, 26-30 cycles per instruction
 // measured on both the fp32 and the bf16 table), so every instruction saved is time saved.
 struct LongPlan {
-    const int4 *chunks;           // [n_chunk_slots] (index o into long_row, first entry, end entry in the stream, ordinal in row)
+    const int4 *chunks;           // [n_chunk_slots] (index o into long_row | -1 = padding, first entry, end entry in the stream, ordinal in row)
     const int32_t *long_row;      // [n_long] row ids with nnz > LONG_T
     const int32_t *long_nch;      // [n_long] chunks of that row
     float *partials;              // [n_chunk_slots, D]  (slot = position in `chunks`)
     int32_t *counters;            // [n_long] arrival tickets (zero between launches)
     int32_t n_long, n_chunk_slots;
 };
-struct SlicePlan {                // per XCD slice x: chunks [cblk[x], cblk[x+1]) (one workgroup each) then short rows [rows[x], rows[x+1]) of rowinfo
+struct SlicePlan {                // per XCD slice x: chunk blocks [cblk[x], cblk[x+1]) then short rows [rows[x], rows[x+1]) of rowinfo
     int32_t cblk[XCDS + 1];
     int32_t rows[XCDS + 1];       // multiples of SLICE_PAD
 };
@@ -446,7 +446,6 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
     constexpr int U = SP ? 4 : SPMM_U;
     __shared__ int2 stage_lds[4][NPW * ST];
-    __shared__ __attribute__((aligned(32))) float part_lds[4][D];     // partial rows of a long-row chunk's four waves
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
@@ -469,30 +468,15 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     }
     const int ncb = a.sp.cblk[x + 1] - a.sp.cblk[x];
     if (j < ncb) {
-        // ---- one chunk of a long row, the whole WORKGROUP on it: the chunk's 64-entry tiles are dealt
-        //      to the 4 waves in contiguous runs and the waves' partial rows meet in LDS (fixed order).
-        //      One wave walking a 512-entry chunk is 8 serial tiles ~ 16 us -- with every long row
-        //      starting at t = 0 that walk was the tail of the launch; four waves finish it in a quarter.
-        const int c = a.sp.cblk[x] + j;
+        // ---- one chunk of a long row, the whole wave on it ----
+        const int c = (a.sp.cblk[x] + j) * 4 + wid;
         const int4 ch = a.lp.chunks[c];
         const int o = ch.x;
+        if (o < 0) return;
         const int64_t row = a.lp.long_row[o];
         const int nch = a.lp.long_nch[o];
-        const int tiles = (ch.z - ch.y + 63) >> 6, per = (tiles + 3) >> 2;
-        const int nparts = (tiles + per - 1) / per;                  // waves of this chunk that have work (>= 1)
-        if (wid >= nparts) return;                                    // (the barrier counts surviving waves only)
-        const int64_t t0 = ch.y + (int64_t)wid * per * 64, t1 = min((int64_t)ch.z, t0 + (int64_t)per * 64);
-        Acc acc = row_gather<D, TI, SP>(PackedSrc{a.pk}, t0, t1, src, lane, stage_lds[wid]);
-        if (nparts > 1) {
-            if (lane < LPR) storev<C>(&part_lds[wid][lane * C], acc);
-            __syncthreads();
-            if (wid != 0) return;
-            if (lane < LPR) {
-                acc = loadv<C>(&part_lds[0][lane * C]);
-                for (int q = 1; q < nparts; q++) acc += loadv<C>(&part_lds[q][lane * C]);
-            }
-        }
-        if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one workgroup, no hand-off
+        Acc acc = row_gather<D, TI, SP>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
+        if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
             if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc);
             return;
         }
@@ -1078,7 +1062,7 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
     copyplan.reserve((size_t)n_order * 4);
     int64_t n_pk = 0;
     for (int x = 0; x < XCDS; x++) {
-        sp.cblk[x] = (int32_t)(chunks.size() / 4); sp.rows[x] = (int32_t)(rowinfo.size() / 4);
+        sp.cblk[x] = (int32_t)(chunks.size() / 16); sp.rows[x] = (int32_t)(rowinfo.size() / 4);
         const size_t slice_begin = rowinfo.size();
         for (int64_t p = xs[x]; p < xs[x + 1]; p++) {
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
@@ -1116,9 +1100,10 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             n_pk += rowinfo[i + 2];
         }
         const int32_t pad[4] = {-1, 0, 0, 0};
+        while ((chunks.size() / 4) % 4) chunks.insert(chunks.end(), pad, pad + 4);
         while ((rowinfo.size() / 4) % SLICE_PAD) rowinfo.insert(rowinfo.end(), pad, pad + 4);
     }
-    sp.cblk[XCDS] = (int32_t)(chunks.size() / 4); sp.rows[XCDS] = (int32_t)(rowinfo.size() / 4);
+    sp.cblk[XCDS] = (int32_t)(chunks.size() / 16); sp.rows[XCDS] = (int32_t)(rowinfo.size() / 4);
     lgcn_graph *g = new (std::nothrow) lgcn_graph;
     if (!g) { lgcn_set_error("out of memory"); return 4; }
     g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr; g->pk = nullptr;
