@@ -229,7 +229,7 @@ __device__ __forceinline__ float sum_xor16(float v) {
     const u32x2 r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-template <int ROT> __device__ __forceinline__ float sum_ror(float v) {      // + the lane ROT further in the 16-lane row
+template <int ROT> __device__ __forceinline__ float sum_ror(float v) {      // + the lane ROT positions lower in the 16-lane row (cyclic)
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROT, 0xf, 0xf, false));
 }
 template <int LPR, typename Acc>
@@ -414,15 +414,16 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #endif
 // One batch of U gathers of a lane group walking ITS OWN row: entries u0 .. u0+U-1 of the group's staged
 // row (past the row's end: zero-weight re-read of its last entry -- unconditional loads, see gather_batch).
-template <int D, typename TI, bool SPARSE, int U>
+template <int D, typename TI, bool SPARSE, int U, int GPR = 1>
 __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycnt, int last, const GatherSrc &src, int l,
-                                           typename Geo<D, TI, SPARSE>::Acc &acc) {
+                                           typename Geo<D, TI, SPARSE>::Acc &acc, int sub = 0) {
     typedef Raw<TI, SPARSE> R;
     int2 cv[U]; typename R::T xr[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int e = u0 + u;
-        cv[u] = mystage[min(e, last)];
+        // GPR lane groups share a row: this group takes entries sub, sub+GPR, ... (entry 0 is always valid)
+        cv[u] = mystage[GPR == 1 ? min(e, last) : (mycnt > 0 ? sub + GPR * min(e, last) : 0)];
         if (e >= mycnt) cv[u].y = 0;
     }
 #pragma unroll
@@ -433,7 +434,41 @@ __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycn
 }
 
 // rows per workgroup of a kernel variant: 4 waves x PACKS packs x NPW rows
-template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= 4 ? 1 : 4 / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
+#ifndef SPMM_WAVE_ROWS
+#define SPMM_WAVE_ROWS 1      /* a wave walks packs one after the other until it has done this many rows (1: one pack per wave --
+                                 measured: 4 -> 1 takes the d = 128 layer from 221 to 199 us; more, shorter waves win) */
+#endif
+template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAVE_ROWS ? 1 : SPMM_WAVE_ROWS / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
+// lane groups that share one short row.  A bf16 table row is 8 lanes wide, so 8 rows fit a wave -- but more,
+// shorter waves are what this kernel wants (measured): two groups per bf16 row = 4 rows per wave like fp32.
+#ifndef SPMM_GPR_BF16
+#define SPMM_GPR_BF16 2
+#endif
+#ifndef SPMM_GPR_F32
+#define SPMM_GPR_F32 1
+#endif
+template <int D, typename TI, bool SP> struct RowGeo {
+    static constexpr int NPW = Geo<D, TI, SP>::NPW;
+    static constexpr int WANT = SP ? 1 : (Geo<D, TI, SP>::CPL == 8 ? SPMM_GPR_BF16 : SPMM_GPR_F32);
+    static constexpr int GPR = NPW >= WANT ? WANT : NPW;
+    static constexpr int RPK = NPW / GPR;          // rows of a pack
+};
+// v[lane] + v[lane ^ O], VALU only
+template <int O> __device__ __forceinline__ float sum_xor(float v, int lane) {
+    if (O == 32) return sum_xor32(v);
+    if (O == 16) return sum_xor16(v);
+    if (O == 8) return sum_ror<8>(v);
+    // O == 4: row_ror moves data to HIGHER lanes (lane i receives lane i - n): the partner is 4 below or 4 above
+    const float dn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + 4, 0xf, 0xf, false));
+    const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + 12, 0xf, 0xf, false));
+    return v + ((lane & 4) ? dn : up);
+}
+// sum over the GPR lane groups of a row (groups LPR lanes apart): every one of them ends with the total
+template <int LPR, int GPR> __device__ __forceinline__ float sum_row_groups(float v, int lane) {
+    if (GPR >= 2) v = sum_xor<LPR>(v, lane);
+    if (GPR >= 4) v = sum_xor<(2 * LPR > 32 ? 32 : 2 * LPR)>(v, lane);
+    return v;
+}
 
 template <int D, typename TI, typename TO, int MODE>
 __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
@@ -442,10 +477,13 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     typedef typename G::Acc Acc;
     typedef Raw<TI, SP> R;
     constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
-    constexpr int PACKS = PackGeo<NPW>::PACKS, RPW = PackGeo<NPW>::RPW, RPB = PackGeo<NPW>::RPB;
+    constexpr int GPR = RowGeo<D, TI, SP>::GPR, RPK = RowGeo<D, TI, SP>::RPK;
+    static_assert(GPR == 1 || GPR == 2 || GPR == 4, "one, two or four lane groups per row");
+    static_assert(LPR * GPR <= 64 && (GPR == 1 || LPR >= 4), "lane groups of a row must fit the wave");
+    constexpr int PACKS = PackGeo<RPK>::PACKS, RPW = PackGeo<RPK>::RPW, RPB = PackGeo<RPK>::RPB;
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
     constexpr int U = SP ? 4 : SPMM_U;
-    __shared__ int2 stage_lds[4][NPW * ST];
+    __shared__ int2 stage_lds[4][(RPK * ST > 64 ? RPK * ST : 64)];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
@@ -525,51 +563,52 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     int2 *stage = stage_lds[wid];
 #pragma unroll 1
     for (int pk = 0; pk < PACKS; pk++) {
-        const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)t * RPB + (wid * PACKS + pk) * NPW;
-        // lane r < NPW fetches (row id, first nnz, count) of row r with ONE 16-byte load from the plan
+        const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)t * RPB + (wid * PACKS + pk) * RPK;
+        // lane r < RPK fetches (row id, first entry, count) of row r with ONE 16-byte load from the plan
         int my_row = -1, my_s = 0, my_n = 0;
-        if (lane < NPW) {
+        if (lane < RPK) {
             const int4 ri = a.rowinfo[pos0 + lane];
             my_row = ri.x; my_s = ri.y; my_n = ri.z;
         }
         if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
         // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
         // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
-        int off[NPW + 1];
+        int off[RPK + 1];
         off[0] = 0;
 #pragma unroll
-        for (int r = 0; r < NPW; r++) off[r + 1] = off[r] + __builtin_amdgcn_readlane(my_n, r);
-        const int tot = off[NPW];
+        for (int r = 0; r < RPK; r++) off[r + 1] = off[r] + __builtin_amdgcn_readlane(my_n, r);
+        const int tot = off[RPK];
         const int64_t base = __builtin_amdgcn_readlane(my_s, 0);
-        int2 cvr[NPW];
+        int2 cvr[RPK];
 #pragma unroll
-        for (int it = 0; it < NPW; it++) {
+        for (int it = 0; it < RPK; it++) {
             cvr[it] = make_int2(0, 0);
             if (it * 64 < tot) { const int e = it * 64 + lane; if (e < tot) cvr[it] = a.pk[base + e]; }
         }
-        const int mylen = __shfl(my_n, g);
+        const int myr = g / GPR, sub = g % GPR;      // this lane group's row of the pack, and its share of it
+        const int mylen = __shfl(my_n, myr);
 #pragma unroll
-        for (int it = 0; it < NPW; it++) {
+        for (int it = 0; it < RPK; it++) {
             if (it * 64 < tot) {
                 const int e = it * 64 + lane;
                 int r = 0;
 #pragma unroll
-                for (int k = 1; k < NPW; k++) r += (e >= off[k]) ? 1 : 0;
+                for (int k = 1; k < RPK; k++) r += (e >= off[k]) ? 1 : 0;
                 int o_r = 0;
 #pragma unroll
-                for (int k = 1; k < NPW; k++) o_r = (e >= off[k]) ? off[k] : o_r;
+                for (int k = 1; k < RPK; k++) o_r = (e >= off[k]) ? off[k] : o_r;
                 if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
             }
         }
-        if (lane < NPW && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
+        if (lane < RPK && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
         __builtin_amdgcn_wave_barrier();
-        int mycnt = mylen, maxcnt = 0;
+        int mycnt = GPR == 1 ? mylen : max(0, (mylen - sub + GPR - 1) / GPR), maxcnt = 0;
         if (SP) {
             // keep only the neighbours whose row is flagged: every lane group compacts ITS row in place,
             // LPR entries per round (one bitmap test instruction serves all the groups)
             int maxlen = 0;
 #pragma unroll
-            for (int r = 0; r < NPW; r++) maxlen = max(maxlen, off[r + 1] - off[r]);
+            for (int r = 0; r < RPK; r++) maxlen = max(maxlen, off[r + 1] - off[r]);
             int2 *mine = stage + g * ST;
             int cnt = 0;
             for (int j0 = 0; j0 < maxlen; j0 += LPR) {
@@ -594,21 +633,25 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
             for (int o2 = LPR; o2 < 64; o2 <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o2));
         } else {
 #pragma unroll
-            for (int r = 0; r < NPW; r++) maxcnt = max(maxcnt, off[r + 1] - off[r]);
+            for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, (off[r + 1] - off[r] + GPR - 1) / GPR);
         }
         maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
-        const int2 *mystage = stage + g * ST;
+        const int2 *mystage = stage + myr * ST;
         const int last = max(mycnt - 1, 0);
         Acc acc = zerov<C>();
         // batch depth follows the pack's longest row (8 / 4 / 2 / 1 gathers per lane): a padded gather costs
         // the address path as much as a useful one
         int u0 = 0;
-        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) pack_batch<D, TI, SP, (U >= 8 ? 8 : U)>(mystage, u0, mycnt, last, src, l, acc);
-        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) pack_batch<D, TI, SP, (U >= 4 ? 4 : U)>(mystage, u0, mycnt, last, src, l, acc);
-        for (; maxcnt - u0 > 1; u0 += 2) pack_batch<D, TI, SP, 2>(mystage, u0, mycnt, last, src, l, acc);
-        if (maxcnt - u0 > 0) pack_batch<D, TI, SP, 1>(mystage, u0, mycnt, last, src, l, acc);
-        const int mrow = __shfl(my_row, g);
-        if (mrow >= 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
+        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) pack_batch<D, TI, SP, (U >= 8 ? 8 : U), GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
+        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) pack_batch<D, TI, SP, (U >= 4 ? 4 : U), GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
+        for (; maxcnt - u0 > 1; u0 += 2) pack_batch<D, TI, SP, 2, GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
+        if (maxcnt - u0 > 0) pack_batch<D, TI, SP, 1, GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
+        if (GPR > 1) {
+#pragma unroll
+            for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
+        }
+        const int mrow = __shfl(my_row, myr);
+        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
@@ -890,7 +933,7 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // ---------------------------------------------------------------------------------
 template <int D, typename TI, typename TO, int MODE>
 static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
-    constexpr int RPB = PackGeo<Geo<D, TI, (MODE & M_SPARSE) != 0>::NPW>::RPB;
+    constexpr int RPB = PackGeo<RowGeo<D, TI, (MODE & M_SPARSE) != 0>::RPK>::RPB;
     static_assert(SLICE_PAD % RPB == 0, "slice padding must hold whole workgroups of every variant");
     unsigned grid = 0, widest = 0;
     for (int x = 0; x < XCDS; x++) {
