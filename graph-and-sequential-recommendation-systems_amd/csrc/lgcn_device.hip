@@ -438,7 +438,11 @@ __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycn
 #define SPMM_WAVE_ROWS 1      /* a wave walks packs one after the other until it has done this many rows (1: one pack per wave --
                                  measured: 4 -> 1 takes the d = 128 layer from 221 to 199 us; more, shorter waves win) */
 #endif
-template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAVE_ROWS ? 1 : SPMM_WAVE_ROWS / NPW, RPW = NPW * PACKS, RPB = 4 * RPW; };
+#ifndef SPMM_WPB
+#define SPMM_WPB 1            /* waves per workgroup (1, 2 or 4; the plan pads a slice's chunks to 4 and its rows to 64).  One-wave
+                                 workgroups measured best: 4 -> 2 -> 1 = 5650 -> 5890 -> 5965 steps/s, dense layer 28.7 -> 27.5 -> 26.6 us */
+#endif
+template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAVE_ROWS ? 1 : SPMM_WAVE_ROWS / NPW, RPW = NPW * PACKS, RPB = SPMM_WPB * RPW; };
 // lane groups that share one short row.  A bf16 table row is 8 lanes wide, so 8 rows fit a wave -- but more,
 // shorter waves are what this kernel wants (measured): two groups per bf16 row = 4 rows per wave like fp32.
 #ifndef SPMM_GPR_BF16
@@ -471,7 +475,7 @@ template <int LPR, int GPR> __device__ __forceinline__ float sum_row_groups(floa
 }
 
 template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
+__global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr bool SP = (MODE & M_SPARSE) != 0;
     typedef Geo<D, TI, SP> G;
     typedef typename G::Acc Acc;
@@ -483,7 +487,7 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr int PACKS = PackGeo<RPK>::PACKS, RPW = PackGeo<RPK>::RPW, RPB = PackGeo<RPK>::RPB;
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
     constexpr int U = SP ? 4 : SPMM_U;
-    __shared__ int2 stage_lds[4][(RPK * ST > 64 ? RPK * ST : 64)];
+    __shared__ int2 stage_lds[SPMM_WPB][(RPK * ST > 64 ? RPK * ST : 64)];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
@@ -492,22 +496,22 @@ __global__ void __launch_bounds__(256, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     //  own round trip per workgroup costs what the per-neighbour tests save once a pack's tests are batched)
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
     //  sat on the tail and cost +25 us)
-    if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == 3)
+    if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == SPMM_WPB - 1)
         reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane);
     int x, j;
     if (a.remap) { x = blockIdx.x & (XCDS - 1); j = blockIdx.x >> 3; }
     else {        // slices as contiguous block ranges (placement-independent either way: speed only)
         x = 0; j = blockIdx.x;
         while (x < XCDS - 1) {
-            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB;
+            const int nb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) * (4 / SPMM_WPB) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB;
             if (j < nb) break;
             j -= nb; x++;
         }
     }
-    const int ncb = a.sp.cblk[x + 1] - a.sp.cblk[x];
+    const int ncb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) * (4 / SPMM_WPB);      // the plan counts groups of 4 chunks
     if (j < ncb) {
         // ---- one chunk of a long row, the whole wave on it ----
-        const int c = (a.sp.cblk[x] + j) * 4 + wid;
+        const int c = a.sp.cblk[x] * 4 + j * SPMM_WPB + wid;
         const int4 ch = a.lp.chunks[c];
         const int o = ch.x;
         if (o < 0) return;
@@ -937,12 +941,12 @@ static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     static_assert(SLICE_PAD % RPB == 0, "slice padding must hold whole workgroups of every variant");
     unsigned grid = 0, widest = 0;
     for (int x = 0; x < XCDS; x++) {
-        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB);
+        const unsigned nb = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) * (4 / SPMM_WPB) + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPB);
         grid += nb; widest = nb > widest ? nb : widest;
     }
     if (a.remap) grid = widest * XCDS;
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
 }
 
 template <int D, int MODE>

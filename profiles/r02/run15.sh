@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, GPU run 15: lane groups per row / rows per wave
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02o
+OUT=$ROOT/gpurun_out/r02p
 mkdir -p $OUT
 cd $ROOT
 run_variant() {  # name, env...
@@ -16,10 +16,10 @@ run_variant() {  # name, env...
   echo "variant $name done"
 }
 run_variant base A=1
-for v in f2 b4 f2b4 f4 wr1; do run_variant $v LGCN_LIB_PATH=$ROOT/build/variants/lib_$v.so; done
+for v in wpb1 wpb2; do run_variant $v LGCN_LIB_PATH=$ROOT/build/variants/lib_$v.so; done
 python - <<'PY'
 import json, os
-root = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out/r02o")
+root = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out/r02p")
 for l in open(os.path.join(root, "var_spmm.jsonl")):
     j = json.loads(l); r = j['roofline']
     print("spmm", j['variant'], j['workload'], j['act_dtype'], 'us', round(r['avg_launch_us'], 2))
