@@ -98,9 +98,9 @@ template <int C> __device__ __forceinline__ typename VecF<C>::T loadv_fixed(cons
 }
 
 struct GatherSrc {           // what a row gather reads
-    const void *X;           // [N,D] of TI, or the fixed-point table when SPARSE
+    const void *X;           // [N,D] of TI; SPARSE: the fp32 copy of the flagged gradient rows (k_g32)
     const uint32_t *bm;      // SPARSE: non-zero-row bitmap (global, or the workgroup's LDS copy)
-    float div;               // SPARSE: K+1
+    float div;               // unused by the gathers (K+1; the epilogues take it from SpmmArgs)
 };
 
 // Raw (unconverted) piece of a gathered row: 16 bytes per lane for fp32 AND bf16 tables (4 / 8
@@ -126,18 +126,10 @@ template <> struct Raw<bf16_t, false> {
         return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 8); }
     static __device__ __forceinline__ f32x8 cvt(const T &r, float) { return __builtin_convertvector(r, f32x8); }
 };
-template <typename TI> struct Raw<TI, true> {
-    static constexpr int CPL = 4;
-    typedef fixed4 T;
-    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
-        const long long *p = (const long long *)s.X + (int64_t)col * D + l * 4;
-        return T{*reinterpret_cast<const i64x2 *>(p), *reinterpret_cast<const i64x2 *>(p + 2)}; }
-    static __device__ __forceinline__ f32x4 cvt(const T &r, float div) {
-        f32x4 o;
-        o.x = (float)((double)r.a.x * FIXED_INV) / div; o.y = (float)((double)r.a.y * FIXED_INV) / div;
-        o.z = (float)((double)r.b.x * FIXED_INV) / div; o.w = (float)((double)r.b.y * FIXED_INV) / div;
-        return o; }
-};
+// SPARSE: the flagged rows of Gs, converted once per step from the fixed-point accumulator to fp32 by k_g32
+// (gathering the 512-byte int64 rows and converting every gathered copy -- int64 -> fp64 -> fp32 and a
+// division per element -- made this launch cost as much as a dense layer for a quarter of its gathers)
+template <typename TI> struct Raw<TI, true> : Raw<float, false> {};
 // geometry of one kernel instance: columns per lane, lanes per row, neighbour rows per wave-instruction
 template <int D, typename TI, bool SPARSE> struct Geo {
     static constexpr int CPL = Raw<TI, SPARSE>::CPL, LPR = D / CPL, NPW = 64 / LPR;
@@ -333,6 +325,7 @@ struct SpmmArgs {
     LongPlan lp; SlicePlan sp;
     const void *X; void *Y;
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
+    const float *G32;             // their fp32 copy Gs = G64 / 2^50 / (K+1), valid on the flagged rows (k_g32)
     float *P; float *M; float *V;
     bf16_t *Pb;                   // optional bf16 shadow of P written by the Adam epilogue
     // last kernel of a step (K >= 2): its epilogue zeroes the G64 rows / bitmap bits it consumes and one
@@ -352,7 +345,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
     typedef typename VecF<C>::T V;
     const int64_t off = row * D + l * C;
     if ((MODE & M_ADDG) && bit_set(a.bitmap, (int)row)) {
-        V g = loadv_fixed<C>(a.G64 + off, a.div);
+        V g = loadv<C>(a.G32 + off);          // = (float)(G64 * 2^-50) / (K+1), converted once by k_g32
         acc = g + acc;
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
@@ -408,6 +401,9 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #ifndef SPMM_MIN_WAVES
 #define SPMM_MIN_WAVES 6      /* waves per SIMD the register allocation must allow (<= 80 VGPRs): a wave keeps up to
                                  NPW x 8 row gathers in flight, so residency is not what hides the latency */
+#endif
+#ifndef SPMM_U_SP
+#define SPMM_U_SP 4           /* the same for the sparse first backward layer (few flagged neighbours per row) */
 #endif
 #ifndef SPMM_U
 #define SPMM_U 8              /* gathers in flight per lane in the short-row path */
@@ -486,12 +482,12 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
     static_assert(LPR * GPR <= 64 && (GPR == 1 || LPR >= 4), "lane groups of a row must fit the wave");
     constexpr int PACKS = PackGeo<RPK>::PACKS, RPW = PackGeo<RPK>::RPW, RPB = PackGeo<RPK>::RPB;
     constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
-    constexpr int U = SP ? 4 : SPMM_U;
+    constexpr int U = SP ? SPMM_U_SP : SPMM_U;
     __shared__ int2 stage_lds[SPMM_WPB][(RPK * ST > 64 ? RPK * ST : 64)];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
-    src.X = SP ? (const void *)a.G64 : a.X; src.bm = a.bitmap; src.div = a.div;
+    src.X = SP ? (const void *)a.G32 : a.X; src.bm = a.bitmap; src.div = a.div;
     // (a per-workgroup LDS copy of the row bitmap -- 9 KiB on Gowalla -- was measured: no gain, the copy's
     //  own round trip per workgroup costs what the per-neighbour tests save once a pack's tests are batched)
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
@@ -591,54 +587,64 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
         }
         const int myr = g / GPR, sub = g % GPR;      // this lane group's row of the pack, and its share of it
         const int mylen = __shfl(my_n, myr);
-#pragma unroll
-        for (int it = 0; it < RPK; it++) {
-            if (it * 64 < tot) {
-                const int e = it * 64 + lane;
-                int r = 0;
-#pragma unroll
-                for (int k = 1; k < RPK; k++) r += (e >= off[k]) ? 1 : 0;
-                int o_r = 0;
-#pragma unroll
-                for (int k = 1; k < RPK; k++) o_r = (e >= off[k]) ? off[k] : o_r;
-                if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
-            }
-        }
-        if (lane < RPK && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
-        __builtin_amdgcn_wave_barrier();
         int mycnt = GPR == 1 ? mylen : max(0, (mylen - sub + GPR - 1) / GPR), maxcnt = 0;
-        if (SP) {
-            // keep only the neighbours whose row is flagged: every lane group compacts ITS row in place,
-            // LPR entries per round (one bitmap test instruction serves all the groups)
-            int maxlen = 0;
+        if (!SP) {
 #pragma unroll
-            for (int r = 0; r < RPK; r++) maxlen = max(maxlen, off[r + 1] - off[r]);
-            int2 *mine = stage + g * ST;
-            int cnt = 0;
-            for (int j0 = 0; j0 < maxlen; j0 += LPR) {
-                const int e = j0 + l;
-                const bool valid = e < mylen;
-                int2 cv = make_int2(0, 0);
-                if (valid) cv = mine[e];
-                const bool flag = valid && bit_set(src.bm, cv.x);
-                const unsigned long long m = __ballot(flag);
-                unsigned long long gm = m;
-                if constexpr (LPR < 64) gm = (m >> (g * LPR)) & ((1ull << LPR) - 1ull);
-                const int pos = cnt + __popcll(gm & ((1ull << l) - 1ull));
-                __builtin_amdgcn_wave_barrier();
-                if (flag) mine[pos] = cv;
-                cnt += __popcll(gm);
+            for (int it = 0; it < RPK; it++) {
+                if (it * 64 < tot) {
+                    const int e = it * 64 + lane;
+                    int r = 0;
+#pragma unroll
+                    for (int k = 1; k < RPK; k++) r += (e >= off[k]) ? 1 : 0;
+                    int o_r = 0;
+#pragma unroll
+                    for (int k = 1; k < RPK; k++) o_r = (e >= off[k]) ? off[k] : o_r;
+                    if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
+                }
             }
-            mycnt = cnt;
-            if (cnt == 0 && l == 0) mine[0] = make_int2(0, 0);
-            __builtin_amdgcn_wave_barrier();
-            maxcnt = mycnt;
-#pragma unroll
-            for (int o2 = LPR; o2 < 64; o2 <<= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o2));
-        } else {
+            if (lane < RPK && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
 #pragma unroll
             for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, (off[r + 1] - off[r] + GPR - 1) / GPR);
+        } else {
+            // keep only the neighbours whose row is flagged.  The bitmap words of ALL the pack's entries are
+            // fetched in one round trip straight from the registers the stream landed in, and every entry is
+            // staged at its compacted position in one pass: ballot, popcount of the flagged lanes below it
+            // inside its own row's lane range, plus the row's count from the earlier 64-entry pieces (uniform).
+            uint32_t w[RPK];
+#pragma unroll
+            for (int it = 0; it < RPK; it++) w[it] = (it * 64 < tot) ? src.bm[cvr[it].x >> 5] : 0u;      // col 0 past the end: valid
+            int cntr[RPK];
+#pragma unroll
+            for (int r = 0; r < RPK; r++) cntr[r] = 0;
+#pragma unroll
+            for (int it = 0; it < RPK; it++) {
+                if (it * 64 < tot) {
+                    const int e = it * 64 + lane;
+                    const bool flag = e < tot && ((w[it] >> (cvr[it].x & 31)) & 1u);
+                    const unsigned long long m = __ballot(flag);
+                    int r = 0, o_r = 0, before = cntr[0];
+#pragma unroll
+                    for (int k = 1; k < RPK; k++) { const bool ge = e >= off[k]; r += ge ? 1 : 0; o_r = ge ? off[k] : o_r; before = ge ? cntr[k] : before; }
+                    const int lo = max(o_r - it * 64, 0);                 // first lane of this lane's row in this piece (<= lane)
+                    const unsigned long long below = m & ((1ull << lane) - 1ull) & ~((1ull << lo) - 1ull);
+                    if (flag) stage[r * ST + before + __popcll(below)] = cvr[it];
+#pragma unroll
+                    for (int k = 0; k < RPK; k++) {
+                        const int lk = min(max(off[k] - it * 64, 0), 64), hk = min(max(off[k + 1] - it * 64, 0), 64);
+                        const unsigned long long mk = (hk >= 64 ? ~0ull : (1ull << hk) - 1ull) & ~(lk >= 64 ? ~0ull : (1ull << lk) - 1ull);
+                        cntr[k] += __popcll(m & mk);
+                    }
+                }
+            }
+            mycnt = cntr[0];
+            int lanecnt = cntr[0];       // count of row `lane` (lanes < RPK)
+#pragma unroll
+            for (int k = 1; k < RPK; k++) { mycnt = myr == k ? cntr[k] : mycnt; lanecnt = lane == k ? cntr[k] : lanecnt; }
+            if (lane < RPK && lanecnt == 0) stage[lane * ST] = make_int2(0, 0);       // a valid column for the padding reads
+#pragma unroll
+            for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, cntr[r]);
         }
+        __builtin_amdgcn_wave_barrier();
         maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
         const int2 *mystage = stage + myr * ST;
         const int last = max(mycnt - 1, 0);
@@ -875,6 +881,7 @@ struct SlotArgs {
     const int32_t *users; const int32_t *pos; const int32_t *neg;
     int32_t B; int32_t n_users; int64_t N;
     long long *G64; uint32_t *bitmap;
+    float *G32; float div;                                 // k_g32: fp32 copy of the flagged rows, K+1
     const float *gathered; int32_t shard; int32_t world;   // DP scatter
     const float *terms; float *loss_out; float decay;
 };
@@ -893,6 +900,20 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     f32x4 g = load4(a.gathered + r * blk + ((int64_t)c * a.shard + i) * D + l * 4);
     atomic_add_fixed4(a.G64 + row * D + l * 4, g);
     if (l == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+}
+
+// Gs rows of the batch, once per step: G32[row] = (float)(G64[row] * 2^-50) / (K+1) for every slot's row, after
+// ALL contributions are in (k_bpr_loss / k_scatter / the all-reduce).  Slots that share a row write the same
+// bytes.  The first backward layer gathers these 4-byte rows (and every Horner epilogue adds them) instead of
+// converting the fixed-point rows per gathered copy.
+template <int D>
+__global__ void __launch_bounds__(256) k_g32(SlotArgs a) {
+    constexpr int LPR = D / 4, SPB = 256 / LPR;
+    const int s = blockIdx.x * SPB + threadIdx.x / LPR, l = threadIdx.x % LPR;
+    if (s >= 3 * a.B) return;
+    const int64_t row = slot_row(s / a.B, s % a.B, a.users, a.pos, a.neg, a.n_users, a.N);
+    if (row < 0) return;
+    store4(a.G32 + row * D + l * 4, loadv_fixed<4>(a.G64 + row * D + l * 4, a.div));
 }
 
 // dense data-parallel form: flag the rows of the WHOLE global batch (every rank knows all ids), so the
@@ -1282,6 +1303,7 @@ struct lgcn_ctx {
     int flip;
     void *act[LGCN_MAX_LAYERS + 1];   // act[k] = X_k storage for k = 1..K-1 (K with dense_last; also reused for H)
     int fwd_layers;               // dense forward layers per step: K-1, or K with dense_last
+    float *g32;                   // [N,d] fp32 copy of the step's flagged gradient rows (library-owned; k_g32)
 };
 
 extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
@@ -1303,17 +1325,26 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     for (int k = 0; k <= LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
     x->fwd_layers = c.dense_last ? c.K : c.K - 1;
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
+    // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
+    x->g32 = nullptr;
+    const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
+    if (hipMalloc((void **)&x->g32, gbytes) != hipSuccess || hipMemset(x->g32, 0, gbytes) != hipSuccess) {
+        if (x->g32) (void)hipFree(x->g32);
+        delete x;
+        lgcn_set_error("lgcn_ctx_create: cannot allocate the fp32 gradient-row table (N*d*4 bytes)");
+        return 4;
+    }
     *out = x;
     return 0;
 }
-extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) { delete ctx; }
+extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) { if (ctx) { if (ctx->g32) (void)hipFree(ctx->g32); delete ctx; } }
 extern "C" int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx) { return ctx ? ctx->step : -1; }
 extern "C" void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t s) { if (ctx) ctx->step = s; }
 extern "C" void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr) { if (ctx) ctx->c.lr = lr; }
 
 static SpmmArgs base_spmm(const lgcn_ctx *x) {
     SpmmArgs a = graph_spmm(x->c.graph);
-    a.G64 = (long long *)x->c.G64; a.bitmap = x->c.bitmap + x->flip * x->bm_words;
+    a.G64 = (long long *)x->c.G64; a.G32 = x->g32; a.bitmap = x->c.bitmap + x->flip * x->bm_words;
     a.div = (float)(x->c.K + 1); a.remap = x->c.xcd_remap;
     return a;
 }
@@ -1374,7 +1405,8 @@ static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t
     const lgcn_train_config &c = x->c;
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
-    s.G64 = (long long *)c.G64; s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
+    s.G64 = (long long *)c.G64; s.G32 = x->g32; s.div = (float)(c.K + 1);
+    s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
     s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
     return s;
 }
@@ -1392,10 +1424,14 @@ static void *bwd_buffer(const lgcn_ctx *x, int k) {
 // One layer of the Horner chain h_{k-1} = Gs + A h_k (k = K: sparse input Gs; k = 1: feeds Adam).
 // fused_finish: the Adam launch also zeroes the G64 rows it consumes and reduces the loss (single-GPU
 // and batch-sharded steps, where every rank runs every row); the row-sharded step finishes separately.
-static int backward_layer(lgcn_ctx *x, int k, int32_t B, const float *gathered, int32_t shard, float *loss_out,
-                          bool fused_finish, hipStream_t st) {
+static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
+                          const float *gathered, int32_t shard, float *loss_out, bool fused_finish, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     const bool first = (k == c.K), last = (k == 1);
+    if (first) {        // every contribution is in G64 by now: convert the batch rows once
+        SlotArgs s = slot_args(x, users, pos, neg, B, gathered, shard, 1, loss_out);
+        DISPATCH_D(c.d, hipLaunchKernelGGL((k_g32<D>), dim3(slot_grid(x, B)), dim3(256), 0, st, s));
+    }
     SpmmArgs a = base_spmm(x);
     a.X = first ? nullptr : bwd_buffer(x, k + 1);
     if (!last) a.Y = bwd_buffer(x, k);
@@ -1428,7 +1464,7 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
     x->step += 1;
     // Horner: h_{K-1} = Gs + A Gs (sparse input); h_{k-1} = Gs + A h_k; last one feeds Adam
     for (int k = c.K; k >= 1; k--) {
-        int rc = backward_layer(x, k, B, gathered, shard, loss_out, true, st);
+        int rc = backward_layer(x, k, users, pos, neg, B, gathered, shard, loss_out, true, st);
         if (rc) return rc;
     }
     if (c.K >= 2) { x->flip ^= 1; return 0; }       // next step flags rows in the other bitmap
@@ -1560,7 +1596,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     case LGCN_RS_BWD:                                 // h_{k-1}[owned] = Gs + (A h_k)[owned], k = K..1; k = 1: Adam on the owned rows
         if (k < 1 || k > c.K) { lgcn_set_error("lgcn_rs_phase: backward layer out of range"); return 3; }
         if (k == c.K) x->step += 1;
-        rc = backward_layer(x, k, B_global, gathered, shard, loss_out, false, st);
+        rc = backward_layer(x, k, users, pos, neg, B_global, gathered, shard, loss_out, false, st);
         break;
     case LGCN_RS_FINISH: {                            // zero the batch rows of G64 + their flags, reduce the loss
         if (!loss_out) { lgcn_set_error("lgcn_rs_phase: loss_out is null"); return 3; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, GPU run 10: final parity pass, PMC traffic of the final k_spmm, final bench lines + traces
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02j
+OUT=$ROOT/gpurun_out/r02t
 mkdir -p $OUT
 cd $ROOT
 timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/status.log
