@@ -191,10 +191,10 @@ __device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt,
 // Gather-accumulate the staged tile.  The batch depth follows the (wave-uniform) number of staged
 // neighbours instead of always issuing the deepest batch: a 64-lane gather instruction costs the
 // CU's address path the same whether 1 or all of its row slots are useful.
-template <int D, typename TI, bool SPARSE>
+template <int D, typename TI, bool SPARSE, int UCAP = LGCN_GATHER_U>
 __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane,
                                             typename Geo<D, TI, SPARSE>::Acc &acc) {
-    constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 4 : LGCN_GATHER_U;
+    constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 4 : UCAP;
 #ifdef LGCN_EXP_NO_GATHER
     return;
 #endif
@@ -686,15 +686,19 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// BPR on the batch, two launches (a one-workgroup-per-triplet form kept a CU at 2 resident workgroups and
-// took 30 us; split, every slot row is its own small workgroup).
+// BPR on the batch.
 //
-// k_rows: one 256-thread workgroup per slot (3B slots: user, positive item, negative item of
-//   every triplet).  e = mean_k X_k[row]; the last layer X_K[row] = (A_hat X_{K-1})[row] is
-//   computed on the fly.  The 4 waves split the row's 64-entry tiles (positives are sampled
-//   proportionally to popularity: 1000-neighbour rows are common); a wave without work ends
-//   at once (s_barrier counts only surviving waves), so a typical slot costs one wave.
-//   k_bpr_loss: triplet_loss (below), one lane group per triplet.
+// k_triplet (default): ONE 256-thread workgroup per triplet does everything the batch needs from it:
+//   the three slot rows e = mean_k X_k[row] (user, positive, negative item; the last layer
+//   X_K[row] = (A_hat X_{K-1})[row] is gathered on the fly), then the loss terms and the three gradient
+//   rows (triplet_loss_regs).  A row is cut into units of ROWS_UNIT_TILES 64-entry tiles; unit u of slot c
+//   belongs to wave (c + u) mod 4: a typical triplet costs one unit per slot on waves 0-2 and wave 3 ends at
+//   once, while a hub positive (sampled proportionally to popularity: 1000-neighbour rows are common) is
+//   shared by all four waves.  Partial rows meet in LDS in a fixed order; wave 0 finishes the triplet.
+//   (Round 1/2 history: one workgroup per SLOT + a loss launch = 24.6K waves of which 18K ended after reading
+//   two indices; the launch skeleton alone -- ids, indptr, nothing else -- measured 7.3 of its 16.7 us, and
+//   the slot rows made a round trip through HBM to the 6.7 us loss launch.)
+// k_rows_dense + k_bpr_loss: the same when the last layer was propagated densely (cfg.dense_last).
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -742,15 +746,11 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
 // r = |e_u|^2+|e_p|^2+|e_n|^2 ; gradient rows w.r.t. the propagated table -> fixed-point
 // atomics into G64 + row flags (single GPU / dense DP) or the exchange block (DP rows).
 template <int D>
-__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
+__device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l, const float *u, const float *p, const float *n) {
     constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
-    float u[CPL], p[CPL], n[CPL];
     float ps = 0.f, ns = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
-        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
-        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
-        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
         ps += u[j] * p[j]; ns += u[j] * n[j]; ru += u[j] * u[j]; rp += p[j] * p[j]; rn += n[j] * n[j];
     }
     float rr = ru + rp + rn;
@@ -785,6 +785,20 @@ __device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
     }
 }
 
+// the same from the slot rows k_rows_dense left in ebuf
+template <int D>
+__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
+    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
+    float u[CPL], p[CPL], n[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
+        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
+        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
+    }
+    triplet_loss_regs<D>(a, b, l, u, p, n);
+}
+
 // (Doing this on the last of a triplet's three k_rows workgroups to arrive -- tickets, write-through rows --
 //  removed this launch but cost more than it saved: +9 us on k_rows, every workgroup pays the ticket's
 //  round trip before it can retire; measured 32.3 us fused vs 16.8 + 6.5 us split.)
@@ -799,55 +813,116 @@ __global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
     triplet_loss<D>(a, b, l);
 }
 
-#ifndef BPR_BW
-#define BPR_BW 4
+#ifndef TRIPLET_MIN_WAVES
+#define TRIPLET_MIN_WAVES 4    /* workgroups per CU the register allocation must allow (a 64-VGPR cap spills: measured 27.8 vs 20 us) */
 #endif
-#ifndef ROWS_MIN_TILES
-#define ROWS_MIN_TILES 4       /* a wave takes at least this many 64-entry tiles before the row is split */
+#ifndef TRIPLET_U
+#define TRIPLET_U LGCN_GATHER_U   /* gathers in flight per lane in k_triplet */
 #endif
+#ifndef ROWS_UNIT_TILES
+#define ROWS_UNIT_TILES 2      /* 64-entry tiles per unit of a slot row */
+#endif
+// units u_first, u_first + 4, ... of the row [start, start + n): one wave's share of a slot row.  The next
+// tile's (col,val) pairs are in flight while this tile gathers, across the unit boundaries too.
+template <int D, typename TG, typename ES>
+__device__ __forceinline__ typename Geo<D, TG, false>::Acc
+units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &src, int lane, int2 *stage) {
+    typedef Geo<D, TG, false> G;
+    constexpr int UT = ROWS_UNIT_TILES;
+    typename G::Acc acc = zerov<G::CPL>();
+    const int ntiles = (n + 63) >> 6;
+    int t = u_first * UT;
+    if (t >= ntiles) return acc;
+    int2 cv = make_int2(0, 0);
+    if (t * 64 + lane < n) cv = es.at(start + t * 64 + lane);
+    for (;;) {
+        const int cnt = tile_stage<false>(cv.x, __int_as_float(cv.y), min(64, n - t * 64), src, lane, stage);
+        __builtin_amdgcn_wave_barrier();
+        int tn = t + 1;
+        if (tn % UT == 0) tn += 3 * UT;
+        const bool more = tn < ntiles;
+        if (more && tn * 64 + lane < n) cv = es.at(start + tn * 64 + lane);
+        tile_gather<D, TG, false, TRIPLET_U>(stage, cnt, src, lane, acc);
+        __builtin_amdgcn_wave_barrier();
+        if (!more) break;
+        t = tn;
+    }
+    return reduce_groups<G::LPR>(acc);
+}
+
 // TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
 template <int D, typename TG, typename TI>
-__device__ __forceinline__ void rows_body(const BprArgs &a, const void *Xg, int64_t row, int s0, int s1, int q, int nparts,
-                                          int lane, int2 *stage, float (*part)[D]) {
+__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[4][D], float (*base)[D]) {
     typedef Geo<D, TG, false> G;
-    constexpr int C = G::CPL, LPR = G::LPR;
-    GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
-    typename G::Acc xk = row_gather<D, TG, false>(CsrSrc{a.indices, a.vals}, s0, s1, src, lane, stage);
-    if (nparts > 1) {
-        if (lane < LPR) storev<C>(&part[q][lane * C], xk);
-        __syncthreads();
-        if (q != 0) return;
-        if (lane < LPR) {
-            xk = loadv<C>(&part[0][lane * C]);
-            for (int w = 1; w < nparts; w++) xk += loadv<C>(&part[w][lane * C]);
+    constexpr int C = G::CPL, LPR = G::LPR, UN = 64 * ROWS_UNIT_TILES;
+    constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT;      // lane = column (mod 64) layout of the finishing steps
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const bool bad = triplet_bad(a, b);                 // an out-of-range id voids the whole triplet (err flag; zero terms)
+    if (bad && threadIdx.x == 0) atomicExch(a.err, 1);
+    // everything below is wave-uniform (scalar registers)
+    const int64_t row0 = bad ? 0 : (int64_t)a.users[b], row1 = bad ? 0 : (int64_t)a.pos[b] + a.n_users, row2 = bad ? 0 : (int64_t)a.neg[b] + a.n_users;
+    const int st0 = a.indptr[row0], st1 = a.indptr[row1], st2 = a.indptr[row2];
+    const int n0 = a.indptr[row0 + 1] - st0, n1 = a.indptr[row1 + 1] - st1, n2 = a.indptr[row2 + 1] - st2;
+    if (w == 3 && lane < LPT) {
+        // the spare wave: the K lower layers' rows of the three slots, summed in layer order, while waves 0-2 gather
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int64_t row = c == 0 ? row0 : (c == 1 ? row1 : row2);
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int col = j * LPT + lane;
+                float s = a.X0[row * D + col];
+                for (int k = 1; k < a.K; k++) s += (float)((const TI *)a.Xl[k])[row * D + col];
+                base[c][col] = s;
+            }
         }
     }
-    if (lane < LPR) {       // (issuing these row loads before the gather measured 3 us slower)
-        const int64_t off = row * D + lane * C;
-        typename G::Acc s = loadv<C>(a.X0 + off);
-        for (int k = 1; k < a.K; k++) s += loadv<C>((const TI *)a.Xl[k] + off);
-        s += xk;
-        const float div = (float)(a.K + 1);
-        storev<C>(a.ebuf + (int64_t)blockIdx.x * D + lane * C, s / div);
+    GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
+    bool any = (w == 0 || w == 3);
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {                       // (not unrolled: three inlined copies of the gather loop cost 20 VGPRs)
+        const int stc = c == 0 ? st0 : (c == 1 ? st1 : st2), nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
+        const int u0 = (w - c + 4) & 3, units = (nc + UN - 1) / UN;
+        if (u0 < units) {
+            const typename G::Acc x = units_gather<D, TG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
+            if (lane < LPR) storev<C>(&part[c][w][lane * C], x);
+            any = true;
+        }
     }
+    if (!any) return;                  // s_barrier counts only the surviving waves
+    __syncthreads();
+    if (w != 0 || lane >= LPT) return;
+    // wave 0: finish the three rows and the triplet
+    const float div = (float)(a.K + 1);
+    float e[3][CPT];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int units = ((c == 0 ? n0 : (c == 1 ? n1 : n2)) + UN - 1) / UN;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int col = j * LPT + lane;
+            float xk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (i < units) xk += part[c][(c + i) & 3][col];     // unit 0's wave first
+            e[c][j] = (base[c][col] + xk) / div;
+        }
+    }
+    triplet_loss_regs<D>(a, b, lane, e[0], e[1], e[2]);
 }
 
 template <int D, typename TI>
-__global__ void __launch_bounds__(64 * BPR_BW) k_rows(BprArgs a) {
-    __shared__ int2 stage_lds[BPR_BW][64];
-    __shared__ __attribute__((aligned(32))) float part_lds[BPR_BW][D];
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x / a.B_local, b = blockIdx.x % a.B_local;     // slot-major: [3][B_local]
-    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
-    if (triplet_bad(a, b)) { if (lane == 0 && q == 0) atomicExch(a.err, 1); row = 0; }
-    const int start = a.indptr[row], end = a.indptr[row + 1];
-    const int tiles = (end - start + 63) >> 6, per = max((tiles + BPR_BW - 1) / BPR_BW, ROWS_MIN_TILES);
-    const int nparts = tiles == 0 ? 1 : (tiles + per - 1) / per;          // waves of this slot that have work
-    if (q >= nparts) return;
-    const int s0 = min(end, start + q * per * 64), s1 = min(end, start + (q + 1) * per * 64);
-    if (a.K == 1) rows_body<D, float, TI>(a, a.X0, row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
-    else rows_body<D, TI, TI>(a, a.Xl[a.K - 1], row, s0, s1, q, nparts, lane, stage_lds[q], part_lds);
+__global__ void __launch_bounds__(256, TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
+    __shared__ int2 stage_lds[4][64];
+    __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
+    __shared__ float base_lds[3][D];
+    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
+        a.stale_bitmap[i] = 0u;
+    int2 *stage = stage_lds[threadIdx.x >> 6];
+    if (a.K == 1) triplet_body<D, float, TI>(a, a.X0, stage, part_lds, base_lds);
+    else triplet_body<D, TI, TI>(a, a.Xl[a.K - 1], stage, part_lds, base_lds);
 }
 
 // Slot rows when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row
@@ -1382,7 +1457,7 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.ebuf = c.ebuf;
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
-        // two steps ago still has to be cleared (k_bpr_loss does it on the other ranks)
+        // two steps ago still has to be cleared (k_triplet / k_bpr_loss does it on the other ranks)
         HIP_OK(hipMemsetAsync(a.stale_bitmap, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
         return 0;
     }
@@ -1391,11 +1466,10 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
             const unsigned gd = (unsigned)(((int64_t)3 * B_local + 256 / (D / 4) - 1) / (256 / (D / 4)));
             if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_rows_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
-        }
-        else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows<D, float>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
-        else hipLaunchKernelGGL((k_rows<D, bf16_t>), dim3(3 * B_local), dim3(64 * BPR_BW), 0, st, a);
-        const int tpb = 256 / (D < 64 ? D : 64);
-        hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
+            const int tpb = 256 / (D < 64 ? D : 64);
+            hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
+        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float>), dim3(B_local), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_triplet<D, bf16_t>), dim3(B_local), dim3(256), 0, st, a);
     });
     return 0;
 }
