@@ -12,9 +12,10 @@
 //
 // Algebra used (exact restructuring):
 //  * forward needs dense X_1..X_{K-1} only; the last layer X_K and the layer mean
-//    are evaluated on the <= 3B rows the batch gathers (k_bpr).
+//    are evaluated on the <= 3B rows the batch gathers (k_triplet).
 //  * backward is the Horner chain h_{k-1} = Gs + A h_k, Gs = G/(K+1); Gs has
-//    <= 3B non-zero rows, so the first backward SpMM skips zero rows by bitmap.
+//    <= 3B non-zero rows, so the first backward SpMM skips zero rows by bitmap
+//    and gathers the flagged rows from a fp32 copy made once per step (k_g32).
 //  * the last backward SpMM applies Adam in its epilogue (no dense grad buffer).
 //  * the scatter-add of per-triplet gradient rows uses 64-bit fixed-point integer
 //    atomics (scale 2^50): integer addition is associative, so the result is
@@ -341,10 +342,10 @@ enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
 //   M_ADDG  : add Gs[row] where flagged (Horner term)
 //   M_ADAM  : apply torch.optim.Adam to P/M/V with grad = result, else store to Y
 template <int D, typename TO, int MODE, int C>
-__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc) {
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc, bool flagged) {
     typedef typename VecF<C>::T V;
     const int64_t off = row * D + l * C;
-    if ((MODE & M_ADDG) && bit_set(a.bitmap, (int)row)) {
+    if ((MODE & M_ADDG) && flagged) {      // (the row's bitmap word was fetched before the gathers -- a dependent load here measured +0.3-0.6 % on the step)
         V g = loadv<C>(a.G32 + off);          // = (float)(G64 * 2^-50) / (K+1), converted once by k_g32
         acc = g + acc;
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
@@ -513,9 +514,10 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
         if (o < 0) return;
         const int64_t row = a.lp.long_row[o];
         const int nch = a.lp.long_nch[o];
+        const bool rflag = (MODE & M_ADDG) ? bit_set(a.bitmap, (int)row) : false;
         Acc acc = row_gather<D, TI, SP>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
         if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
-            if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc);
+            if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc, rflag);
             return;
         }
         // Publish the partial WRITE-THROUGH (sc1: 8-byte agent-scope stores, no release fence -- a
@@ -547,7 +549,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
             for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(sp_ + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k == 0) tot = pk.v; else tot += pk.v;
         }
-        spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot);
+        spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot, rflag);
         return;
     }
     // ---- short rows (<= 64 non-zeros): a pack of NPW rows at a time, ONE ROW PER LANE GROUP.  All
@@ -570,6 +572,8 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
             const int4 ri = a.rowinfo[pos0 + lane];
             my_row = ri.x; my_s = ri.y; my_n = ri.z;
         }
+        uint32_t my_fw = 0u;           // bitmap word of this lane's row, in flight under the stream loads
+        if ((MODE & M_ADDG) && my_row >= 0) my_fw = a.bitmap[my_row >> 5];
         if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
         // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
         // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
@@ -661,7 +665,8 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
             for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
         }
         const int mrow = __shfl(my_row, myr);
-        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc);
+        const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
+        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
@@ -799,9 +804,7 @@ __device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
     triplet_loss_regs<D>(a, b, l, u, p, n);
 }
 
-// (Doing this on the last of a triplet's three k_rows workgroups to arrive -- tickets, write-through rows --
-//  removed this launch but cost more than it saved: +9 us on k_rows, every workgroup pays the ticket's
-//  round trip before it can retire; measured 32.3 us fused vs 16.8 + 6.5 us split.)
+// the loss launch of the dense_last form (k_triplet does the same inside the triplet's own workgroup)
 template <int D>
 __global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
     constexpr int LPT = D < 64 ? D : 64, TPB = 256 / LPT;     // lanes per triplet, triplets per workgroup
@@ -928,7 +931,7 @@ __global__ void __launch_bounds__(256, TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
 // Slot rows when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row
 // reads.  On graphs whose positives concentrate on hub items (a popularity-weighted mean item degree in the
 // thousands: the synthetic Yelp / Amazon shapes) the slots together hold several times the graph's non-zeros
-// -- one more dense SpMM is then far cheaper than k_rows' per-slot gathers (236 -> ~50 us at B = 8192).
+// -- one more dense SpMM is then far cheaper than per-slot gathers (236 -> ~50 us at B = 8192).
 template <int D, typename TI>
 __global__ void __launch_bounds__(256) k_rows_dense(BprArgs a) {
     constexpr int LPR = D / 4, SPB = 256 / LPR;

@@ -462,6 +462,49 @@ def test_fused_steps_other_dims_vs_oracle(pkg, oracle, tmp_path, d, K, act):
     m.check_device_errors()
 
 
+@pytest.mark.parametrize("d,K,act", [(64, 3, "fp32"), (32, 1, "fp32"), (256, 2, "fp32"), (128, 3, "bf16")])
+def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act):
+    """k_triplet cuts a slot row into units of 128 non-zeros dealt to the workgroup's four waves: batches whose user /
+    positive / negative rows sit exactly on and around every unit and wave-wrap boundary (1 ... 1300 non-zeros,
+    item hubs of 350 / 700 / 1400), duplicates of the same hub in one batch, vs the oracle's stageOne."""
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640, 1025, 1300]
+    n_users = m_items = 1400
+    path = os.path.join(str(tmp_path), f"units{d}")
+    os.makedirs(path, exist_ok=True)
+    rng = np.random.Generator(np.random.PCG64(d + K))
+    with open(os.path.join(path, "train.txt"), "w") as f, open(os.path.join(path, "test.txt"), "w") as ft:
+        for u in range(n_users):
+            if u < len(lens):
+                items = np.arange(lens[u])                                  # exactly lens[u] non-zeros, hub items included
+            else:
+                base = [0, 1] + ([2] if u % 2 == 0 else []) + ([3] if u % 4 == 0 else [])
+                extra = 4 + rng.choice(m_items - 4, size=int(rng.integers(1, 20)), replace=False)
+                items = np.unique(np.concatenate([np.asarray(base, dtype=np.int64), extra]))
+            f.write(f"{u} " + " ".join(map(str, items.tolist())) + "\n")
+            ft.write(f"{u} {int(rng.integers(0, m_items))}\n")
+    w = pkg.world
+    w.configure(["--dataset", "units", "--tensorboard", "0", "--layer", str(K), "--recdim", str(d),
+                 "--bpr_batch", "128", "--act_dtype", act, "--dense_last", "0"])
+    ds = pkg.dataloader.Loader(w.config, path=path)
+    pkg.utils.set_seed(3)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    adj = ds.getSparseGraphCSR()
+    deg = np.diff(adj.indptr)
+    assert sorted(set(deg[:len(lens)].tolist())) == sorted(lens) and deg[n_users] >= 1380 and 650 < deg[n_users + 2] < 760
+    tr = oracle.Trainer(ds.n_users, adj.indptr, adj.indices, adj.data, m._table.cpu().numpy().copy(), K, w.config['decay'], w.config['lr'])
+    bpr = pkg.utils.BPRLoss(m, w.config)
+    tol = 3e-6 if act == "fp32" else 3e-4
+    for step in range(3):
+        u = np.concatenate([np.arange(len(lens)), rng.integers(0, n_users, 108 - len(lens) + 20 * (step == 0))])[:128 if step else 100]
+        p = np.concatenate([np.asarray([0, 0, 1, 2, 3, 2, 0, 3]), rng.integers(0, m_items, len(u) - 8)])      # hub positives, duplicated
+        n = np.concatenate([rng.integers(0, m_items, len(u) - 4), np.asarray([1, 2, 3, 0])])
+        l_ref = tr.stageOne(u, p, n)
+        l_got = bpr.stageOne(_dev(u), _dev(p), _dev(n))
+        assert abs(l_got - l_ref) < tol * 10, (step, l_got, l_ref)
+        np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=tol if act == "fp32" else 2e-3)
+    m.check_device_errors()
+
+
 def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
     """Checkpoint surface of main.py:56-87: model.state_dict() (keys embedding_user/item.weight) +
     bpr.opt.state_dict() (torch-Adam format: step / exp_avg / exp_avg_sq) saved after 2 steps,
