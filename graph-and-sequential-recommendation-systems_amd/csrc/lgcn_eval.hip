@@ -19,9 +19,9 @@
 //   * the accumulator layout puts a user on a lane (col = lane & 31) and 16 of the tile's items in its
 //     registers, so the train-positive mask is a 32-bit word per user (built one tile ahead from the
 //     sorted train CSR by a cursor whose next entry is always already loaded) and the running top-K
-//     is per lane: a threshold compare per score, and only a score above the lane's current K-th best
-//     touches its K-entry list in LDS (replace the minimum, rescan for the new minimum).  The lists
-//     of the two lanes of a user are merged and sorted once at the end.
+//     is per lane: a threshold compare per score marks the candidates of a tile, and only those touch the
+//     lane's list in LDS (replace the minimum, rescan for the new minimum), one per round for all lanes
+//     together.  The lists of the two lanes of a user are merged and sorted once at the end.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -34,6 +34,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define EVAL_KMAX 32
 #define EVAL_NEG_INF (-3.0e38f)
+#ifndef EVAL_PARTS
+#define EVAL_PARTS 2          /* workgroups per user block (<= 4) when two fit a CU */
+#endif
 
 struct EvalArgs {
     const float *E; int32_t n_users, m_items;
@@ -41,18 +44,21 @@ struct EvalArgs {
     const int64_t *train_ptr; const int32_t *train_idx;
     int32_t K;
     int32_t *out_items; float *out_scores;
+    // the item sweep split over gridDim.y workgroups per user block (two co-resident workgroups per CU overlap
+    // one's list maintenance with the other's MFMAs): each writes its sorted partial list here, k_eval_merge picks
+    int32_t *part_items; float *part_scores;      // [n_eval, gridDim.y, K] or NULL (gridDim.y == 1: straight to out_*)
 };
 
-template <int D>
+template <int D, int KS>        // KS: list slots per lane (a multiple of 4, >= K)
 __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
     constexpr int HALF = D / 2, RS = D + 4;            // row stride of the LDS item tile (floats)
     constexpr int LPT = 32 * D * 4 / 16 / 256;          // 16-byte pieces per thread per item tile
     static_assert(LPT >= 1, "tile smaller than the workgroup");
     __shared__ __attribute__((aligned(16))) float tile_lds[2][32 * RS];
-    // per-lane candidate lists: always EVAL_KMAX slots (slots >= K hold +inf: never the minimum, never output),
-    // 16-byte aligned rows so the minimum scan is 8 independent ds_read_b128
-    __shared__ __attribute__((aligned(16))) float list_s[256][EVAL_KMAX + 4];
-    __shared__ int32_t list_i[256][EVAL_KMAX + 1];
+    // per-lane candidate lists: KS slots (slots >= K hold +inf: never the minimum, never output),
+    // 16-byte aligned rows so the minimum scan is KS/4 independent ds_read_b128
+    __shared__ __attribute__((aligned(16))) float list_s[256][KS + 4];
+    __shared__ int32_t list_i[256][KS + 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int K = a.K;
@@ -74,16 +80,22 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
     // ---- train-positive cursor (lower lane of the pair walks it; the mask is shared with the upper one)
     int64_t tp = 0, tend = 0;
     int32_t nid = 0x7fffffff, nnid = 0x7fffffff;
+    const int ntiles_all = (a.m_items + 31) / 32;
+    const int t_begin = (int)((int64_t)ntiles_all * blockIdx.y / gridDim.y), t_end = (int)((int64_t)ntiles_all * (blockIdx.y + 1) / gridDim.y);
     if (have && h == 0) {
         tp = a.train_ptr[uid]; tend = a.train_ptr[uid + 1];
+        if (t_begin > 0) {                                      // first train positive inside this workgroup's item range
+            int64_t lo = tp, hi = tend;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.train_idx[mid] < t_begin * 32) lo = mid + 1; else hi = mid; }
+            tp = lo;
+        }
         if (tp < tend) nid = a.train_idx[tp];
         if (tp + 1 < tend) nnid = a.train_idx[tp + 1];
     }
-    for (int k = 0; k < EVAL_KMAX; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = -1; }
+    for (int k = 0; k < KS; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = -1; }
     float thr = EVAL_NEG_INF;      // the lane's K-th best so far
     int pmin = 0;                  // where it sits in the list
 
-    const int ntiles = (a.m_items + 31) / 32;
     // piece p of a tile: item row p / (D/4), 16-byte column p % (D/4)
     f32x4 pre[LPT];
     auto load_tile = [&](int t) {
@@ -101,12 +113,12 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
             *reinterpret_cast<f32x4 *>(&tile_lds[buf][r * RS + c * 4]) = pre[q];
         }
     };
-    load_tile(0);
-    store_tile(0);
+    load_tile(t_begin);
+    store_tile(t_begin & 1);
     __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
+    for (int t = t_begin; t < t_end; t++) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);                  // in flight under this tile's MFMAs
+        if (t + 1 < t_end) load_tile(t + 1);                   // in flight under this tile's MFMAs
         // ---- mask of this tile's train positives for my user
         const int base = t * 32;
         uint32_t mask = 0;
@@ -127,26 +139,45 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[s + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[s + 3], acc, 0, 0, 0);
         }
-        // ---- my 16 scores: item row = (reg & 3) + 8 * (reg >> 2) + 4 * h
+        // ---- my 16 scores: item row = (reg & 3) + 8 * (reg >> 2) + 4 * h.  First only MARK the ones that can
+        //      enter the user's top K: above this lane's K-th best AND not below the partner lane's (the other
+        //      half of the user's items: K items at or above that score already exist).  Then the marked scores
+        //      are inserted one per round, all lanes together: the rounds of a tile are the LARGEST number of
+        //      marked scores any lane of the workgroup has (the waves meet at the tile's barrier), not the number
+        //      of score positions where some lane inserts -- mid-sweep that is 1-2 rounds instead of 5-10.
+        const float othr = __shfl_xor(thr, 32);
+        uint32_t pend = 0;
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
             float sc = acc[reg];
             if ((mask >> row) & 1u) sc = -1024.0f;                      // Procedure.py:181
             if (base + row >= a.m_items) sc = EVAL_NEG_INF;             // past the table
-            if (sc > thr) {
-                list_s[tid][pmin] = sc; list_i[tid][pmin] = base + row;
-                // new minimum: all slots read at once (no dependent LDS round trips), then a register scan
-                f32x4 q[EVAL_KMAX / 4];
+            acc[reg] = sc;
+            if (sc > thr && sc >= othr) pend |= 1u << reg;
+        }
+        while (__any(pend != 0u)) {
+            if (pend != 0u) {
+                const int reg = __builtin_ctz(pend);
+                pend &= pend - 1u;
+                float sc = acc[0];
 #pragma unroll
-                for (int k4 = 0; k4 < EVAL_KMAX / 4; k4++) q[k4] = *reinterpret_cast<const f32x4 *>(&list_s[tid][4 * k4]);
-                float m = q[0].x; int pm = 0;
+                for (int r = 1; r < 16; r++) sc = reg == r ? acc[r] : sc;
+                if (sc > thr) {                                         // thr may have risen since the marking
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    list_s[tid][pmin] = sc; list_i[tid][pmin] = base + row;
+                    // new minimum: all slots read at once (no dependent LDS round trips), then a register scan
+                    f32x4 q[KS / 4];
 #pragma unroll
-                for (int k = 1; k < EVAL_KMAX; k++) { const float v = q[k / 4][k % 4]; if (v < m) { m = v; pm = k; } }
-                thr = m; pmin = pm;
+                    for (int k4 = 0; k4 < KS / 4; k4++) q[k4] = *reinterpret_cast<const f32x4 *>(&list_s[tid][4 * k4]);
+                    float m = q[0].x; int pm = 0;
+#pragma unroll
+                    for (int k = 1; k < KS; k++) { const float v = q[k / 4][k % 4]; if (v < m) { m = v; pm = k; } }
+                    thr = m; pmin = pm;
+                }
             }
         }
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        if (t + 1 < t_end) store_tile(buf ^ 1);
         __syncthreads();
     }
     // ---- merge the two lanes of a user, sort descending (ties: lower item id first)
@@ -163,9 +194,34 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
                 }
             }
             if (bw >= 0) list_i[bw][bk] = -1;                  // taken
-            a.out_items[slot * K + r] = bw >= 0 ? bi : -1;
-            if (a.out_scores) a.out_scores[slot * K + r] = best;
+            if (a.part_items) {
+                const int64_t o = (slot * gridDim.y + blockIdx.y) * K + r;
+                a.part_items[o] = bw >= 0 ? bi : -1; a.part_scores[o] = best;
+            } else {
+                a.out_items[slot * K + r] = bw >= 0 ? bi : -1;
+                if (a.out_scores) a.out_scores[slot * K + r] = best;
+            }
         }
+    }
+}
+
+// top K of a user's P sorted partial lists (descending, ties: lower item id first): a P-way merge by one thread
+__global__ void __launch_bounds__(256) k_eval_merge(EvalArgs a, int P) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_eval) return;
+    const int K = a.K;
+    int cur[4] = {0, 0, 0, 0};
+    for (int r = 0; r < K; r++) {
+        float best = EVAL_NEG_INF * 2.0f; int bi = 0x7fffffff, bp = -1;
+        for (int p = 0; p < P; p++) {
+            if (cur[p] >= K) continue;
+            const int64_t o = (s * P + p) * K + cur[p];
+            const int id = a.part_items[o]; const float v = a.part_scores[o];
+            if (id >= 0 && (v > best || (v == best && id < bi))) { best = v; bi = id; bp = p; }
+        }
+        if (bp >= 0) cur[bp]++;
+        a.out_items[s * K + r] = bp >= 0 ? bi : -1;
+        if (a.out_scores) a.out_scores[s * K + r] = best;
     }
 }
 
@@ -231,15 +287,32 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     }
     if (K < 1 || K > EVAL_KMAX || K > m_items) { lgcn_set_error("lgcn_eval_topk: K must be in 1..32 and <= m_items"); return 3; }
     if (n_eval == 0) return 0;
-    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores};
-    const unsigned grid = (unsigned)((n_eval + 127) / 128);
+    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr};
+    const unsigned blocks = (unsigned)((n_eval + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    // two workgroups per user block when two of them fit a CU (LDS: d <= 64 with 20 list slots) and the sweep is long
+    // (measured on Gowalla: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
+    const int parts = (d <= 64 && K <= 20 && m_items >= 4096) ? EVAL_PARTS : 1;
+    void *tmp = nullptr;
+    if (parts > 1) {
+        const size_t n = (size_t)n_eval * parts * K;
+        if (hipMallocAsync(&tmp, n * (sizeof(int32_t) + sizeof(float)), st) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: cannot allocate the partial lists"); return 4; }
+        a.part_items = (int32_t *)tmp; a.part_scores = (float *)((int32_t *)tmp + n);
+    }
+    const dim3 grid(blocks, parts);
+#define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20>), grid, dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((k_eval_topk<DD, 32>), grid, dim3(256), 0, st, a); } while (0)
     switch (d) {
-    case 32: hipLaunchKernelGGL((k_eval_topk<32>), dim3(grid), dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL((k_eval_topk<64>), dim3(grid), dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((k_eval_topk<128>), dim3(grid), dim3(256), 0, st, a); break;
-    case 256: hipLaunchKernelGGL((k_eval_topk<256>), dim3(grid), dim3(256), 0, st, a); break;
-    default: lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
+    case 32: EVAL_LAUNCH(32); break;
+    case 64: EVAL_LAUNCH(64); break;
+    case 128: EVAL_LAUNCH(128); break;
+    case 256: EVAL_LAUNCH(256); break;
+    default: if (tmp) (void)hipFreeAsync(tmp, st); lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
+    }
+#undef EVAL_LAUNCH
+    if (parts > 1) {
+        hipLaunchKernelGGL(k_eval_merge, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, st, a, parts);
+        (void)hipFreeAsync(tmp, st);
     }
     if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_topk: launch failed"); return 10; }
     return 0;
