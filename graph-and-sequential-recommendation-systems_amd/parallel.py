@@ -118,6 +118,7 @@ class DataParallelBPR:
                 raise ValueError("row-sharded propagation exchanges gradient rows (reduce='rows')")
             self.ranges = row_ranges(recmodel._adj.indptr, recmodel.n_users, self.world)
         self._comm = None          # lgcn_dp handle: the library's own RCCL communicator (lazy)
+        self._comm_ok = None       # decided collectively at the first epoch
         self._gathered = None
 
     # -- the library's RCCL communicator: collectives are issued from C on the kernels' stream --------
@@ -136,6 +137,30 @@ class DataParallelBPR:
             _lib.check(lib.lgcn_dp_init(box[0], self.world, self.rank, C.byref(h)), "lgcn_dp_init")
             self._comm = h
         return self._comm
+
+    def _own_communicator_ok(self):
+        """True when every rank joined the library's communicator.  If any rank could not (librccl not
+        loadable, ncclCommInitRank refused), ALL ranks drop theirs and the epoch runs as the per-step loop
+        over torch.distributed's RCCL collectives instead -- same kernels, same results, one host call per
+        step instead of per epoch.  (Row-sharded propagation has no such loop and raises.)"""
+        if self._comm_ok is None:
+            err = None
+            try:
+                self._communicator()
+            except Exception as e:      # noqa: BLE001 -- reported below, decided collectively
+                err = e
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.model._table.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            self._comm_ok = int(flag.item()) == 0
+            if not self._comm_ok:
+                self.close()
+                if self.shard == 'rows':
+                    raise RuntimeError(f"row-sharded propagation needs the library's RCCL communicator: {err or 'another rank failed'}")
+                if self.rank == 0:
+                    import sys
+                    print(f"[lgcn] own RCCL communicator unavailable ({err or 'another rank failed'}); "
+                          "using torch.distributed collectives per step", file=sys.stderr)
+        return self._comm_ok
 
     def close(self):
         if self._comm is not None:
@@ -158,7 +183,7 @@ class DataParallelBPR:
         m = self.model
         dev = m._table.device
         T = int(users.numel())
-        if dev.type != 'cuda' or os.environ.get("LGCN_DP_PYTHON_LOOP") == "1":
+        if dev.type != 'cuda' or os.environ.get("LGCN_DP_PYTHON_LOOP") == "1" or not self._own_communicator_ok():
             out = [self._step(users[t:t + global_batch], pos[t:t + global_batch], neg[t:t + global_batch])
                    for t in range(0, T, global_batch)]
             return torch.stack(out)
