@@ -81,7 +81,14 @@ def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=N
 
     total_batch = len(users) // B + 1
     lr = bpr.opt.param_groups[0]['lr']
-    losses = Recmodel.fused_epoch(users, posItems, negItems, B, lr=lr)     # [steps,3] on device
+    if getattr(Recmodel, 'has_variants', False):
+        # popularity gate / item-item smoothing: the reference's own loop (Procedure.py:56-66) over stageOne
+        was_lazy, bpr.lazy = bpr.lazy, True
+        per = [bpr.stageOne(users[t:t + B], posItems[t:t + B], negItems[t:t + B]) for t in range(0, len(users), B)]
+        bpr.lazy = was_lazy
+        losses = torch.stack(per).reshape(-1, 1)
+    else:
+        losses = Recmodel.fused_epoch(users, posItems, negItems, B, lr=lr)     # [steps,3] on device
     if prefetch:
         with timer(name="Sample"):
             _prefetch_next_epoch(dataset)                                   # host work under the GPU's epoch
@@ -175,7 +182,7 @@ def _test_fused(Recmodel, ev, max_K):
     """Procedure.py:162-192 in two launches: lgcn_eval_topk (scores on the matrix cores + train mask +
     top-K, no score matrix in memory) and lgcn_eval_metrics (hits, precision / recall / NDCG, sums)."""
     lib = _lib.load()
-    E = Recmodel.propagated_table()
+    E = Recmodel.rating_table()
     n = len(ev.users)
     dev = E.device
     topk = torch.empty(n, max_K, dtype=torch.int32, device=dev)

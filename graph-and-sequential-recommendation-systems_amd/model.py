@@ -9,8 +9,12 @@ All propagation / loss / optimiser arithmetic runs in the hand-written gfx950
 kernels behind include/lgcn_hip.h.  There is no torch.sparse.mm path and no CPU
 fallback: on a machine without a HIP device every compute method raises.
 
-Out of scope: the popularity gate and the item-item
-smoothing branch; asking for them raises NotImplementedError.
+The fork's optional branches (8f-4) are supported on the autograd path: the
+popularity gate (model.py:66-96,139-157,176-181: two small dense MLPs, torch ops) and the item-item
+smoothing (model.py:99-109,228-229: one more CSR SpMM, the same HIP kernel on the item-item graph, with
+its transpose in backward).  With either switched on, BPRLoss.stageOne is the reference's own sequence
+(bpr_loss -> backward -> torch.optim.Adam over ALL parameters) with every propagation in the HIP
+kernels; the fused single-launch-chain step covers the default model only.
 """
 import ctypes as C
 
@@ -46,6 +50,19 @@ class _Propagate(torch.autograd.Function):
         return h[:m.n_users], h[m.n_users:], None
 
 
+class _I2ISmooth(torch.autograd.Function):
+    """model.py:228-229: items + alpha * (I2I @ items); backward g + alpha * (I2I^T @ g)."""
+
+    @staticmethod
+    def forward(ctx, items, model):
+        ctx.model = model
+        return model._i2i_apply(items, transpose=False)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.model._i2i_apply(grad, transpose=True), None
+
+
 class LightGCN(nn.Module):
     def __init__(self, config, dataset):
         super().__init__()
@@ -57,12 +74,6 @@ class LightGCN(nn.Module):
         self.latent_dim = config['latent_dim_rec']
         self.n_layers = config['lightGCN_n_layers']
         self.keep_prob = config.get('keep_prob', 0.6)
-        if bool(config.get('use_pop_gate', False)):
-            raise NotImplementedError("popularity gate (model.py:66-96) is outside the MI355X hot path")
-        if bool(config.get('use_item_item', False)) and config.get('i2i_path', None):
-            raise NotImplementedError("item-item smoothing (model.py:99-109) is outside the MI355X hot path")
-        self.use_pop_gate = False
-        self.use_item_item = False
         if self.latent_dim not in (32, 64, 128, 256):
             raise ValueError("latent_dim_rec must be 32, 64, 128 or 256 for the HIP kernels")
         if not (1 <= self.n_layers <= _lib.MAX_LAYERS):
@@ -81,6 +92,37 @@ class LightGCN(nn.Module):
         self._table = table
         self._rebind()
 
+        # popularity gate (model.py:66-96): same modules, built in the same order -> same initial weights
+        self.use_pop_gate = bool(config.get('use_pop_gate', False))
+        self.pop_hidden = int(config.get('pop_hidden', 32))
+        self.gate_hidden = int(config.get('gate_hidden', 64))
+        self.gate_entropy_coeff = float(config.get('gate_entropy_coeff', 1e-4))
+        self.pop_gate_temp = float(config.get('pop_gate_temp', 1.0))
+        if self.use_pop_gate:
+            counts = torch.clamp(torch.from_numpy(np.asarray(dataset.items_D)).float(), min=0.0)
+            pop = torch.log1p(counts)
+            self.item_pop_scalar = (pop - pop.mean()) / (pop.std() + 1e-8)
+            self.pop_mlp = nn.Sequential(nn.Linear(1, self.pop_hidden), nn.ReLU(), nn.Linear(self.pop_hidden, self.latent_dim))
+            self.gate_mlp = nn.Sequential(nn.Linear(self.latent_dim * 2, self.gate_hidden), nn.ReLU(), nn.Linear(self.gate_hidden, 1))
+        else:
+            self.item_pop_scalar, self.pop_mlp, self.gate_mlp = None, None, None
+
+        # item-item graph (model.py:99-109): a CSR [m_items, m_items] from an .npz; unreadable -> warning, off
+        self.use_item_item = bool(config.get('use_item_item', False))
+        self.i2i_alpha = float(config.get('i2i_alpha', 0.0))
+        self._i2i = None
+        if self.use_item_item and config.get('i2i_path', None):
+            try:
+                import scipy.sparse as sp
+                m = sp.load_npz(config['i2i_path']).tocsr().astype(np.float32)
+                if m.shape != (self.m_items, self.m_items):
+                    raise ValueError(f"shape {m.shape} is not ({self.m_items}, {self.m_items})")
+                m.sort_indices()
+                self._i2i = m
+                world.cprint(f"[I2I] loaded {config['i2i_path']}, nnz={m.nnz}")
+            except Exception as e:      # noqa: BLE001 -- the reference warns and goes on without it
+                world.cprint(f"[I2I] WARNING: cannot load {config['i2i_path']}: {e}")
+
         self._adj = dataset.getSparseGraphCSR() if hasattr(dataset, 'getSparseGraphCSR') else None
         if self._adj is None:                       # generic BasicDataset: COO -> CSR
             g = dataset.getSparseGraph().coalesce().cpu()
@@ -97,6 +139,7 @@ class LightGCN(nn.Module):
         self._Graph = None
         self._dev = None            # device-side state (graph, workspace, context)
         self._cache = None          # propagated embeddings memoised between invalidate_cache() calls
+        self._rating_cache = None
         self.f = nn.Sigmoid()
 
     # -- parameters live in one table ------------------------------------------------
@@ -111,6 +154,11 @@ class LightGCN(nn.Module):
             self._table = new
             self._drop_device_state()
         self._rebind()
+        for mod in (self.pop_mlp, self.gate_mlp):
+            if mod is not None:
+                mod._apply(fn)
+        if self.item_pop_scalar is not None:
+            self.item_pop_scalar = fn(self.item_pop_scalar)
         for p in (self.embedding_user.weight, self.embedding_item.weight):
             if p.grad is not None:
                 p.grad = fn(p.grad)
@@ -247,6 +295,37 @@ class LightGCN(nn.Module):
     def _spmm(self, x):
         return self._state()['graph'].spmm(x.float(), _lib.F32)
 
+    @property
+    def i2i_active(self):
+        return self.use_item_item and self._i2i is not None and self.i2i_alpha > 0.0
+
+    @property
+    def has_variants(self):
+        """True when a branch outside the fused step is on (BPRLoss then takes the autograd path)."""
+        return self.use_pop_gate or self.i2i_active
+
+    def _i2i_apply(self, x, transpose):
+        st = self._state()
+        key = 'i2i_t' if transpose else 'i2i'
+        if key not in st:
+            m = self._i2i.T.tocsr() if transpose else self._i2i
+            m.sort_indices()
+            dev = self._table.device
+            st[key] = _lib.Graph(torch.from_numpy(m.indptr.astype(np.int32)).to(dev), torch.from_numpy(m.indices.astype(np.int32)).to(dev),
+                                 torch.from_numpy(m.data.astype(np.float32)).to(dev), d_max=self.latent_dim)
+        x = x.contiguous().float()
+        return x + self.i2i_alpha * st[key].spmm(x, _lib.F32)
+
+    def _fuse_item_embeddings(self, items_emb):
+        """model.py:139-157: gate * items + (1 - gate) * pop_vec, gate = sigmoid(gate_mlp([items, pop_vec]) / T)."""
+        pop_vec = self.pop_mlp(self.item_pop_scalar.unsqueeze(1))
+        gate_logit = self.gate_mlp(torch.cat([items_emb, pop_vec], dim=1))
+        if self.pop_gate_temp != 1.0:
+            gate_logit = gate_logit / self.pop_gate_temp
+        gate = torch.sigmoid(gate_logit)
+        self._last_item_gate = gate
+        return gate * items_emb + (1.0 - gate) * pop_vec
+
     def _propagate_dense(self):
         st = self._state()
         N, d, K = self.n_users + self.m_items, self.latent_dim, self.n_layers
@@ -265,51 +344,78 @@ class LightGCN(nn.Module):
     def invalidate_cache(self):
         """Hook probed by main.py:190-191 before each Test."""
         self._cache = None
+        self._rating_cache = None
 
     def train(self, mode=True):
-        self._cache = None
+        self.invalidate_cache()
         return super().train(mode)
 
     def propagated_table(self):
-        """The [N,d] fp32 table computer() splits into users / items, memoised between
-        invalidate_cache() / train() calls (what the fused evaluation kernels read)."""
+        """The [N,d] fp32 table computer() splits into users / items (item-item smoothing included), memoised
+        between invalidate_cache() / train() calls."""
         if self._cache is None:
             with torch.no_grad():
-                self._cache = self._propagate_dense()
+                out = self._propagate_dense()
+                if self.i2i_active:
+                    out = torch.cat([out[:self.n_users], self._i2i_apply(out[self.n_users:], transpose=False)], dim=0)
+                self._cache = out
         return self._cache
+
+    def rating_table(self):
+        """What getUsersRating scores with (model.py:114-123): the propagated users and the FINAL item
+        embeddings (popularity-gated when the gate is on).  This is what the fused evaluation kernels read."""
+        if not self.use_pop_gate:
+            return self.propagated_table()
+        if getattr(self, '_rating_cache', None) is None:
+            with torch.no_grad():
+                out = self.propagated_table()
+                self._rating_cache = torch.cat([out[:self.n_users], self._fuse_item_embeddings(out[self.n_users:])], dim=0).contiguous()
+        return self._rating_cache
 
     def computer(self):
         """model.py:201-231 -> (all_users [n_users,d], all_items [m_items,d])."""
         if not self.training and not torch.is_grad_enabled():
             out = self.propagated_table()       # eval: propagate once instead of once per user batch
-        elif torch.is_grad_enabled() and (self.embedding_user.weight.requires_grad
-                                          or self.embedding_item.weight.requires_grad):
+            return out[:self.n_users, :], out[self.n_users:, :]
+        if torch.is_grad_enabled() and (self.embedding_user.weight.requires_grad
+                                        or self.embedding_item.weight.requires_grad):
             out = _Propagate.apply(self.embedding_user.weight, self.embedding_item.weight, self)
         else:
             out = self._propagate_dense()
-        return out[:self.n_users, :], out[self.n_users:, :]
+        all_users, all_items = out[:self.n_users, :], out[self.n_users:, :]
+        if self.i2i_active:                      # model.py:228-229
+            all_items = _I2ISmooth.apply(all_items, self) if all_items.requires_grad else self._i2i_apply(all_items, False)
+        return all_users, all_items
 
     def getUsersRating(self, users):
         all_users, all_items = self.computer()
-        u_emb = all_users[users]
-        return torch.matmul(u_emb, all_items.t())
+        i_emb = self._fuse_item_embeddings(all_items) if self.use_pop_gate else all_items
+        return torch.matmul(all_users[users], i_emb.t())
 
     def getEmbedding(self, users, pos_items, neg_items):
         all_users, all_items = self.computer()
-        return all_users[users], all_items[pos_items], all_items[neg_items], all_users, all_items
+        i_emb = self._fuse_item_embeddings(all_items) if self.use_pop_gate else all_items
+        return all_users[users], i_emb[pos_items], i_emb[neg_items], all_users, all_items
 
     def bpr_loss(self, users, pos, neg):
-        """model.py:162-183 (unfused, autograd-capable): (bpr, reg_loss)."""
+        """model.py:162-183 (unfused, autograd-capable): (bpr [- entropy term of the gate], reg_loss)."""
         u, pos_e, neg_e, _, _ = self.getEmbedding(users, pos, neg)
         pos_scores = torch.sum(u * pos_e, dim=1)
         neg_scores = torch.sum(u * neg_e, dim=1)
         bpr = -torch.mean(F.logsigmoid(pos_scores - neg_scores))
         reg_loss = (0.5 * (u.norm(2).pow(2) + pos_e.norm(2).pow(2) + neg_e.norm(2).pow(2))) / float(u.shape[0])
-        return bpr, reg_loss
+        loss = bpr
+        if self.use_pop_gate and hasattr(self, "_last_item_gate"):
+            gates = torch.cat([self._last_item_gate[pos], self._last_item_gate[neg]], dim=0)
+            gates = torch.clamp(gates, 1e-6, 1.0 - 1e-6)
+            entropy = -(gates * torch.log(gates) + (1 - gates) * torch.log(1 - gates)).mean()
+            loss = loss - self.gate_entropy_coeff * entropy
+        return loss, reg_loss
 
     def forward(self, users, items):
         all_users, all_items = self.computer()
-        return (all_users[users] * all_items[items]).sum(dim=1)
+        i_emb = self._fuse_item_embeddings(all_items) if self.use_pop_gate else all_items
+        return (all_users[users] * i_emb[items]).sum(dim=1)
 
     # -- fused path (what BPRLoss.stageOne calls) ------------------------------------------
     @staticmethod
@@ -321,6 +427,9 @@ class LightGCN(nn.Module):
     def fused_step(self, users, pos, neg, loss_out=None, lr=None):
         """One BPRLoss.stageOne (utils.py:53-64) in the HIP kernels.  Returns a device
         tensor [3] = (bpr + decay*reg, bpr, reg); no host synchronisation."""
+        if self.has_variants:
+            raise RuntimeError("the fused step covers the default model; with the popularity gate or item-item smoothing "
+                               "use BPRLoss.stageOne (autograd path over the same HIP propagation kernels)")
         dev = self._table.device
         users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
         B = int(users.numel())
@@ -333,12 +442,14 @@ class LightGCN(nn.Module):
             loss_out = torch.empty(3, dtype=torch.float32, device=dev)
         _lib.check(lib.lgcn_train_step(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
                                        _lib.tp(loss_out), _lib.current_stream()), "lgcn_train_step")
-        self._cache = None
+        self.invalidate_cache()
         return loss_out
 
     def fused_epoch(self, users, pos, neg, batch_size, lr=None):
         """The loop of main.py:223-225 over already-shuffled device id arrays, one C call.
         Returns a device tensor [steps,3] of per-step (loss, bpr, reg)."""
+        if self.has_variants:
+            raise RuntimeError("fused_epoch covers the default model; loop BPRLoss.stageOne for the optional branches")
         dev = self._table.device
         users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
         T = int(users.numel())
@@ -350,7 +461,7 @@ class LightGCN(nn.Module):
         losses = torch.empty(steps, 3, dtype=torch.float32, device=dev)
         _lib.check(lib.lgcn_train_epoch(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), T, int(batch_size),
                                         _lib.tp(losses), _lib.current_stream()), "lgcn_train_epoch")
-        self._cache = None
+        self.invalidate_cache()
         return losses
 
     def check_device_errors(self):

@@ -97,6 +97,8 @@ class DataParallelBPR:
         from .utils import _AdamView
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if getattr(recmodel, 'has_variants', False):
+            raise NotImplementedError("data-parallel training covers the default model (no popularity gate / item-item smoothing)")
         self.model = recmodel
         self.group = group
         self.world = dist.get_world_size(group)

@@ -79,11 +79,28 @@ class BPRLoss:
         self.model = recmodel
         self.weight_decay = config['decay']
         self.lr = config['lr']
-        self.opt = _AdamView(recmodel.parameters(), lr=self.lr).bind(recmodel)
+        # the optional branches (popularity gate, item-item smoothing) train through autograd and a plain
+        # torch Adam over ALL parameters -- the reference's own sequence, utils.py:53-64
+        self.fused = not getattr(recmodel, 'has_variants', False)
+        if self.fused:
+            self.opt = _AdamView(recmodel.parameters(), lr=self.lr).bind(recmodel)
+        else:
+            self.opt = optim.Adam(recmodel.parameters(), lr=self.lr)
         recmodel.config['decay'] = self.weight_decay
         self.lazy = False          # True: stageOne returns a 0-dim device tensor (no host sync)
 
     def stageOne(self, users, pos, neg):
+        if not self.fused:
+            m = self.model
+            dev = m._table.device
+            users, pos, neg = (torch.as_tensor(np.asarray(t) if not torch.is_tensor(t) else t).to(dev).long() for t in (users, pos, neg))
+            loss, reg_loss = m.bpr_loss(users, pos, neg)
+            loss = loss + reg_loss * self.weight_decay
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            m.invalidate_cache()
+            return loss.detach() if self.lazy else loss.cpu().item()
         lr = self.opt.param_groups[0]['lr']
         out = self.model.fused_step(users, pos, neg, lr=lr)
         if self.lazy:

@@ -7,12 +7,13 @@ path, and nothing of the reference's source text is written to the repo: the
 outputs are data only (inputs + expected outputs as .npz / .json / .txt
 interaction lists).
 
-Usage:  python tests/golden/make_golden.py [tiny] [lastfm] [gowalla] [gowalla_long]
+Usage:  python tests/golden/make_golden.py [tiny] [lastfm] [gowalla] [gowalla_long] [tiny_gate] [tiny_i2i] [tiny_gate_i2i]
 
 What the reference pieces are (all paths relative to
 /root/reference/LightGCN_work/code):
   dataloader.Loader / getSparseGraph     dataloader.py:51-246
-  model.LightGCN (computer, bpr_loss)    model.py:37-231
+  model.LightGCN (computer, bpr_loss)    model.py:37-231 (incl. the optional popularity gate :66-96,139-181 and
+                                         item-item smoothing :99-109,228-229 -- targets tiny_gate / tiny_i2i)
   utils.BPRLoss.stageOne                 utils.py:38-64
   utils.UniformSample_original(_python)  utils.py:68-110
   utils.shuffle / minibatch / set_seed   utils.py:114-151
@@ -401,6 +402,99 @@ def gen_gowalla_samplers(out_dir):
     shutil.rmtree(work, ignore_errors=True)
 
 
+def make_tiny_i2i(train_dir, out_npz):
+    """Item-item matrix for the tiny dataset (our own construction, an INPUT fixture): co-occurrence
+    R^T R without the diagonal, every row scaled to sum 1 (fp32 CSR)."""
+    import scipy.sparse as sp
+    rows, cols = [], []
+    with open(os.path.join(train_dir, "train.txt")) as f:
+        for l in f:
+            c = l.split()
+            rows += [int(c[0])] * (len(c) - 1)
+            cols += [int(x) for x in c[1:]]
+    n_users, m_items = max(rows) + 1, max(cols) + 1
+    R = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_users, m_items))
+    C = (R.T @ R).tolil()
+    C.setdiag(0)
+    C = C.tocsr()
+    C.eliminate_zeros()
+    rs = np.asarray(C.sum(axis=1)).ravel()
+    rs[rs == 0] = 1.0
+    C = sp.diags((1.0 / rs).astype(np.float32)) @ C
+    C = C.tocsr().astype(np.float32)
+    C.sort_indices()
+    sp.save_npz(out_npz, C)
+    return C
+
+
+def gen_variant(tag, gate, i2i, out_dir):
+    """The fork's optional branches on the tiny dataset: popularity gate (model.py:66-96,139-157,176-181)
+    and item-item smoothing (model.py:99-109,228-229), through the reference's own model / BPRLoss."""
+    os.makedirs(out_dir, exist_ok=True)
+    work = tempfile.mkdtemp(prefix="golden_" + tag)
+    make_tiny(work)
+    K, d, B = 3, 64, 64
+    import torch
+    world, dataloader, model, utils, Procedure = import_reference("tiny")
+    world.config["lightGCN_n_layers"], world.config["latent_dim_rec"], world.config["bpr_batch_size"] = K, d, B
+    world.config["use_pop_gate"] = bool(gate)
+    alpha = 0.3
+    if i2i:
+        i2i_path = os.path.join(out_dir, "i2i_tiny.npz")
+        make_tiny_i2i(work, i2i_path)
+        world.config["use_item_item"], world.config["i2i_path"], world.config["i2i_alpha"] = True, i2i_path, alpha
+    dataset = dataloader.Loader(world.config, path=work)
+    utils.sample_ext = False
+    utils.set_seed(world.seed)
+    Recmodel = model.LightGCN(world.config, dataset).to(world.device)
+    assert (Recmodel.i2i_adj is not None) == bool(i2i)
+    bpr = utils.BPRLoss(Recmodel, world.config)
+    meta = {"tag": tag, "K": K, "d": d, "B": B, "use_pop_gate": bool(gate), "use_item_item": bool(i2i),
+            "i2i_alpha": alpha if i2i else 0.0, "seed": world.seed, "lr": world.config["lr"], "decay": world.config["decay"],
+            "pop_hidden": world.config["pop_hidden"], "gate_hidden": world.config["gate_hidden"],
+            "gate_entropy_coeff": world.config["gate_entropy_coeff"], "pop_gate_temp": world.config["pop_gate_temp"],
+            "torch": torch.__version__}
+    out = {}
+
+    def dump(prefix):
+        for k, v in Recmodel.state_dict().items():
+            out[prefix + k] = v.detach().numpy().copy()
+    dump("P0.")
+    with torch.no_grad():
+        au, ai = Recmodel.computer()
+        out["computer_users"], out["computer_items"] = au.numpy().copy(), ai.numpy().copy()
+        out["rating_users_0_9"] = Recmodel.getUsersRating(torch.arange(10)).numpy().copy()
+    meta["test_epoch0"] = ref_test(world, utils, Procedure, dataset, Recmodel, 100)
+    rng = np.random.Generator(np.random.PCG64(7))
+    batches = []
+    for _ in range(4):
+        bu = rng.integers(0, dataset.n_users, B)
+        bp = np.array([dataset.allPos[u][rng.integers(0, len(dataset.allPos[u]))] for u in bu])
+        bn = rng.integers(0, dataset.m_items, B)
+        batches.append((bu.astype(np.int64), bp.astype(np.int64), bn.astype(np.int64)))
+    out["batches"] = np.asarray(batches)                               # [4, 3, B]
+    bu, bp, bn = (torch.tensor(x).long() for x in batches[0])
+    loss, reg = Recmodel.bpr_loss(bu, bp, bn)
+    total = loss + reg * world.config["decay"]
+    Recmodel.zero_grad()
+    total.backward()
+    meta["b_loss"], meta["b_reg"], meta["b_total"] = float(loss), float(reg), float(total)
+    for k, prm in Recmodel.named_parameters():
+        out["G0." + k] = prm.grad.numpy().copy()
+    Recmodel.zero_grad()
+    losses = []
+    for (bu, bp, bn) in batches[1:]:
+        losses.append(bpr.stageOne(torch.tensor(bu).long(), torch.tensor(bp).long(), torch.tensor(bn).long()))
+    meta["step_losses"] = [float(x) for x in losses]
+    dump("P3.")
+    meta["test_after3"] = ref_test(world, utils, Procedure, dataset, Recmodel, 100)
+    np.savez_compressed(os.path.join(out_dir, f"golden_{tag}.npz"), **out)
+    with open(os.path.join(out_dir, f"golden_{tag}.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, json.dumps(meta, sort_keys=True)[:500])
+    shutil.rmtree(work, ignore_errors=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "lastfm", "gowalla"]
     # each target runs in a fresh interpreter: `world` parses argv at import and the
@@ -421,6 +515,8 @@ if __name__ == "__main__":
         gen_gowalla_samplers(os.path.join(HERE, "gowalla"))
     elif w == "gowalla":
         gen_gowalla(os.path.join(HERE, "gowalla"), 1, "short")
+    elif w in ("tiny_gate", "tiny_i2i", "tiny_gate_i2i"):
+        gen_variant(w[5:], "gate" in w, "i2i" in w, os.path.join(HERE, "tiny"))
     elif w == "gowalla_long":
         gen_gowalla(os.path.join(HERE, "gowalla"), 10, "long")
     else:

@@ -505,6 +505,70 @@ def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act):
     m.check_device_errors()
 
 
+@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
+def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag):
+    """the fork's popularity gate (model.py:66-96,139-157,176-181) and item-item smoothing
+    (model.py:99-109,228-229) against fixtures captured from the reference itself on the tiny dataset
+    (tests/golden/make_golden.py tiny_gate / tiny_i2i / tiny_gate_i2i): initial parameters bit for bit (same
+    modules built in the same order from seed 2020), computer(), ratings, Test metrics, bpr_loss and the
+    gradient of EVERY parameter, then three stageOne steps (torch Adam over all parameters) and the metrics after."""
+    gz = np.load(os.path.join(tiny.dir, f"golden_{tag}.npz"))
+    meta = json.load(open(os.path.join(tiny.dir, f"golden_{tag}.json")))
+    d = os.path.join(str(tmp_path), "tiny_" + tag)
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(tiny.dir, f), os.path.join(d, f))
+    w = pkg.world
+    w.configure([])
+    w.dataset = "tiny"
+    w.config.update({'lightGCN_n_layers': meta["K"], 'latent_dim_rec': meta["d"], 'bpr_batch_size': meta["B"], 'decay': meta["decay"],
+                     'lr': meta["lr"], 'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"],
+                     'i2i_path': os.path.join(tiny.dir, "i2i_tiny.npz") if meta["use_item_item"] else None, 'i2i_alpha': meta["i2i_alpha"],
+                     'eval_fused': 1})
+    w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    pkg.utils.set_seed(meta["seed"])
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    assert m.has_variants
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(k[3:] for k in gz.files if k.startswith("P0."))          # the reference's keys
+    for k, v in sd.items():
+        assert np.array_equal(v.cpu().numpy(), gz["P0." + k]), k
+    m.eval()
+    with torch.no_grad():
+        au, ai = m.computer()
+        np.testing.assert_allclose(au.cpu().numpy(), gz["computer_users"], rtol=2e-5, atol=2e-7)
+        np.testing.assert_allclose(ai.cpu().numpy(), gz["computer_items"], rtol=2e-5, atol=2e-7)
+        np.testing.assert_allclose(m.getUsersRating(torch.arange(10, device=DEV)).cpu().numpy(), gz["rating_users_0_9"], rtol=1e-4, atol=2e-6)
+    for fused in (1, 0):                       # the MFMA top-K kernels and the torch harness both see the final item table
+        w.config['eval_fused'] = fused
+        r = pkg.Procedure.Test(ds, m, 0)
+        for k in ("precision", "recall", "ndcg"):
+            np.testing.assert_allclose(np.asarray(r[k], np.float64), meta["test_epoch0"][k], rtol=0, atol=1e-6)
+    m.train()
+    b = gz["batches"]
+    loss, reg = m.bpr_loss(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
+    assert abs(float(loss) - meta["b_loss"]) < 2e-6 and abs(float(reg) - meta["b_reg"]) < 2e-6
+    m.zero_grad()
+    (loss + reg * meta["decay"]).backward()
+    for k, prm in m.named_parameters():
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), gz["G0." + k], rtol=5e-4, atol=2e-8, err_msg=k)
+    m.zero_grad()
+    bpr = pkg.utils.BPRLoss(m, w.config)
+    assert not bpr.fused
+    for i in range(3):
+        l = bpr.stageOne(_dev(b[i + 1, 0]), _dev(b[i + 1, 1]), _dev(b[i + 1, 2]))
+        assert abs(l - meta["step_losses"][i]) < 5e-6, (i, l, meta["step_losses"][i])
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), gz["P3." + k], rtol=0, atol=2e-5, err_msg=k)
+    r = pkg.Procedure.Test(ds, m, 0)
+    for k in ("precision", "recall", "ndcg"):
+        np.testing.assert_allclose(np.asarray(r[k], np.float64), meta["test_after3"][k], rtol=0, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        m.fused_step(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
+    w.configure([])
+
+
 def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
     """Checkpoint surface of main.py:56-87: model.state_dict() (keys embedding_user/item.weight) +
     bpr.opt.state_dict() (torch-Adam format: step / exp_avg / exp_avg_sq) saved after 2 steps,

@@ -331,3 +331,37 @@ def test_sampler_invariants(pkg, tiny, tmp_path):
     assert len(S) == ds.trainDataSize
     for u, p, n in S:
         assert p in pos_sets[u] and n not in pos_sets[u]
+
+
+@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
+def test_optional_branches_construct_like_the_reference(pkg, tmp_path, tag):
+    """Popularity gate / item-item smoothing: same state_dict keys and bit-identical initial
+    parameters as the reference (fixtures captured by tests/golden/make_golden.py tiny_*), on the CPU;
+    the fused step refuses the model, compute needs the GPU."""
+    import json, shutil
+    from conftest import GOLDEN
+    tiny = os.path.join(GOLDEN, "tiny")
+    gz = np.load(os.path.join(tiny, f"golden_{tag}.npz"))
+    meta = json.load(open(os.path.join(tiny, f"golden_{tag}.json")))
+    d = str(tmp_path)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(tiny, f), os.path.join(d, f))
+    w = pkg.world
+    w.configure([])
+    w.dataset = "tiny"
+    w.config.update({'lightGCN_n_layers': meta["K"], 'latent_dim_rec': meta["d"], 'bpr_batch_size': meta["B"],
+                     'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"],
+                     'i2i_path': os.path.join(tiny, "i2i_tiny.npz") if meta["use_item_item"] else None, 'i2i_alpha': meta["i2i_alpha"]})
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    pkg.utils.set_seed(meta["seed"])
+    m = pkg.model.LightGCN(w.config, ds)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(k[3:] for k in gz.files if k.startswith("P0."))
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), gz["P0." + k]), k
+    assert m.has_variants and m.i2i_active == meta["use_item_item"] and m.use_pop_gate == meta["use_pop_gate"]
+    assert not pkg.utils.BPRLoss(m, w.config).fused
+    w.config.update({'use_item_item': True, 'i2i_path': os.path.join(d, "missing.npz"), 'i2i_alpha': 0.5, 'use_pop_gate': False})
+    m2 = pkg.model.LightGCN(w.config, ds)            # unreadable file: the reference warns and trains without it
+    assert not m2.i2i_active and not m2.has_variants
+    w.configure([])
