@@ -341,8 +341,12 @@ enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
 
 //   M_ADDG  : add Gs[row] where flagged (Horner term)
 //   M_ADAM  : apply torch.optim.Adam to P/M/V with grad = result, else store to Y
+// Adam's operands of one row piece, fetched under the LAST gather batch of a pack (see pack_batch)
+template <int C> struct AdamPre { typename VecF<C>::T p, m, v; bool have; };
+
 template <int D, typename TO, int MODE, int C>
-__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc, bool flagged) {
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc, bool flagged,
+                                              const AdamPre<C> *pre = nullptr) {
     typedef typename VecF<C>::T V;
     const int64_t off = row * D + l * C;
     if ((MODE & M_ADDG) && flagged) {      // (the row's bitmap word was fetched before the gathers -- a dependent load here measured +0.3-0.6 % on the step)
@@ -358,7 +362,9 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         }
     }
     if (MODE & M_ADAM) {
-        V p = loadv<C>(a.P + off), m = loadv<C>(a.M + off), v = loadv<C>(a.V + off);
+        V p, m, v;
+        if (pre && pre->have) { p = pre->p; m = pre->m; v = pre->v; }
+        else { p = loadv<C>(a.P + off); m = loadv<C>(a.M + off); v = loadv<C>(a.V + off); }
         m = m + a.w1 * (acc - m);                       // exp_avg.lerp_(grad, 1-beta1)
         v = v * a.beta2 + (a.omb2 * acc) * acc;         // mul_(beta2).addcmul_(g,g,1-beta2)
         V denom;
@@ -403,6 +409,12 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #define SPMM_MIN_WAVES 6      /* waves per SIMD the register allocation must allow (<= 80 VGPRs): a wave keeps up to
                                  NPW x 8 row gathers in flight, so residency is not what hides the latency */
 #endif
+#ifndef SPMM_MIN_WAVES_ADAM
+#define SPMM_MIN_WAVES_ADAM 5    /* the fp32 +Adam variant holds P/M/V pieces across its last batch: 84 VGPRs */
+#endif
+#ifndef SPMM_ADAM_PREFETCH
+#define SPMM_ADAM_PREFETCH 1   /* Adam's P/M/V of a short row are loaded under the pack's last gather batch */
+#endif
 #ifndef SPMM_U_SP
 #define SPMM_U_SP 4           /* the same for the sparse first backward layer (few flagged neighbours per row) */
 #endif
@@ -411,9 +423,11 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #endif
 // One batch of U gathers of a lane group walking ITS OWN row: entries u0 .. u0+U-1 of the group's staged
 // row (past the row's end: zero-weight re-read of its last entry -- unconditional loads, see gather_batch).
-template <int D, typename TI, bool SPARSE, int U, int GPR = 1>
+template <int D, typename TI, bool SPARSE, int U, int GPR = 1, bool PRE = false>
 __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycnt, int last, const GatherSrc &src, int l,
-                                           typename Geo<D, TI, SPARSE>::Acc &acc, int sub = 0) {
+                                           typename Geo<D, TI, SPARSE>::Acc &acc, int sub = 0,
+                                           const SpmmArgs *a = nullptr, int64_t off = -1, bool final_batch = false,
+                                           AdamPre<Geo<D, TI, SPARSE>::CPL> *pre = nullptr) {
     typedef Raw<TI, SPARSE> R;
     int2 cv[U]; typename R::T xr[U];
 #pragma unroll
@@ -425,6 +439,11 @@ __device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycn
     }
 #pragma unroll
     for (int u = 0; u < U; u++) xr[u] = R::load(src, cv[u].x, D, l);
+    if (PRE && final_batch && off >= 0) {       // the pack's last gathers are in flight: Adam's operands ride the same round trip
+        constexpr int C = Geo<D, TI, SPARSE>::CPL;
+        pre->p = loadv<C>(a->P + off); pre->m = loadv<C>(a->M + off); pre->v = loadv<C>(a->V + off);
+        pre->have = true;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u], src.div);
@@ -472,7 +491,7 @@ template <int LPR, int GPR> __device__ __forceinline__ float sum_row_groups(floa
 }
 
 template <int D, typename TI, typename TO, int MODE>
-__global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
+__global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) == 4) ? SPMM_MIN_WAVES_ADAM : SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr bool SP = (MODE & M_SPARSE) != 0;
     typedef Geo<D, TI, SP> G;
     typedef typename G::Acc Acc;
@@ -655,18 +674,25 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, SPMM_MIN_WAVES) k_spmm(SpmmArgs
         Acc acc = zerov<C>();
         // batch depth follows the pack's longest row (8 / 4 / 2 / 1 gathers per lane): a padded gather costs
         // the address path as much as a useful one
+        const int mrow = __shfl(my_row, myr);
+        // (fp32 tables only: with a bf16 table the kernel is already at its register budget and the operands spill --
+        //  measured 6940 vs 7420 steps/s; fp32: 6339 vs 6306)
+        constexpr bool PRE = SPMM_ADAM_PREFETCH && (MODE & M_ADAM) != 0 && sizeof(TI) == 4;
+        AdamPre<C> pre; pre.have = false;
+        const int64_t poff = (PRE && mrow >= 0 && sub == 0) ? (int64_t)mrow * D + l * C : -1;
         int u0 = 0;
-        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) pack_batch<D, TI, SP, (U >= 8 ? 8 : U), GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
-        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) pack_batch<D, TI, SP, (U >= 4 ? 4 : U), GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
-        for (; maxcnt - u0 > 1; u0 += 2) pack_batch<D, TI, SP, 2, GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
-        if (maxcnt - u0 > 0) pack_batch<D, TI, SP, 1, GPR>(mystage, u0, mycnt, last, src, l, acc, sub);
+#define PACK_BATCH(UU) pack_batch<D, TI, SP, UU, GPR, PRE>(mystage, u0, mycnt, last, src, l, acc, sub, &a, poff, maxcnt - u0 <= UU, &pre)
+        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) PACK_BATCH((U >= 8 ? 8 : U));
+        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) PACK_BATCH((U >= 4 ? 4 : U));
+        for (; maxcnt - u0 > 1; u0 += 2) PACK_BATCH(2);
+        if (maxcnt - u0 > 0) PACK_BATCH(1);
+#undef PACK_BATCH
         if (GPR > 1) {
 #pragma unroll
             for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
         }
-        const int mrow = __shfl(my_row, myr);
         const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
-        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag);
+        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag, PRE ? &pre : nullptr);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
