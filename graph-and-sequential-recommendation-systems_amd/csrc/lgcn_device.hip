@@ -296,7 +296,9 @@ row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int l
 // ---------------------------------------------------------------------------------
 #define LONG_T 64             /* rows with more non-zeros than one tile leave the short path */
 #define SLICE_PAD 64          /* short rows of a slice are padded to a multiple of this (>= rows per workgroup of every variant) */
-#define SHORT_WIN 512         /* window of the length sort */
+#ifndef SHORT_WIN
+#define SHORT_WIN 2048        /* window of the length sort (measured 128 / 512 / 1024 / 2048 / 4096 / 8192: 6082 / 6330 / 6403 / 6400 / 6378 / 6329 steps/s) */
+#endif
 #ifndef LONG_CH
 #define LONG_CH 512           /* measured on Gowalla: 64 -> 58 us, 128 -> 40, 256 -> 34, 512 -> 32.5, 768 -> 39, none -> 57 */
 #endif
