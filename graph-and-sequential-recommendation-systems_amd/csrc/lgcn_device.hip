@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
 }
 
 #ifndef TRIPLET_MIN_WAVES
-#define TRIPLET_MIN_WAVES 4    /* workgroups per CU the register allocation must allow (a 64-VGPR cap spills: measured 27.8 vs 20 us) */
+#define TRIPLET_MIN_WAVES 4    /* bf16 tables: a 64-VGPR cap spills (7290 vs 7610 steps/s); fp32 tables fit 64 without (8 workgroups per CU, +0.4 %) */
 #endif
 #ifndef TRIPLET_U
 #define TRIPLET_U LGCN_GATHER_U   /* gathers in flight per lane in k_triplet */
@@ -944,7 +944,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
 }
 
 template <int D, typename TI>
-__global__ void __launch_bounds__(256, TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
+__global__ void __launch_bounds__(256, sizeof(TI) == 4 ? 8 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
     __shared__ int2 stage_lds[4][64];
     __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
     __shared__ float base_lds[3][D];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool (GPU): where does a dense SpMM launch spend its time?  Times the Gowalla launch on
-the whole graph, on the short rows only (<= 64 nnz) and on the long rows only, fp32 and bf16 tables."""
+the whole graph, on the short rows only (<= 64 nnz), on the long rows only (and their single-chunk / split parts), fp32 and bf16 tables."""
 import importlib, io, contextlib, json, os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,8 @@ deg = np.diff(adj.indptr)
 ip, ix, vv = (torch.from_numpy(x).to(dev) for x in (adj.indptr.astype(np.int32), adj.indices.astype(np.int32), adj.data))
 L = pkg._lib; lib = L.load()
 N = adj.shape[0]
-sets = {"all": order, "short": order[deg[order] <= 64], "long": order[deg[order] > 64]}
+sets = {"all": order, "short": order[deg[order] <= 64], "long": order[deg[order] > 64],
+        "mid (65..512, one chunk)": order[(deg[order] > 64) & (deg[order] <= 512)], "hub (> 512, split)": order[deg[order] > 512]}
 for name, rows in sets.items():
     g = L.Graph(ip, ix, vv, d_max=64, row_order=rows, xcd_start=xs if name == "all" else None)
     for dt, tdt in ((0, torch.float32), (1, torch.bfloat16)):
