@@ -48,8 +48,6 @@ def sample_epoch_to_device(dataset, device):
     return users, pos, neg
 
 
-_NEXT_EPOCH = {}          # id(dataset) -> (users, pos, neg, ready event): --prefetch_epoch 1
-
 
 def _prefetch_next_epoch(dataset):
     """Sample + shuffle + upload the NEXT epoch on a side stream while the GPU still runs this one.
@@ -61,7 +59,7 @@ def _prefetch_next_epoch(dataset):
         u, p, n = sample_epoch_to_device(dataset, world.device)
         ev = torch.cuda.Event()
         ev.record(side)
-    _NEXT_EPOCH[id(dataset)] = (u, p, n, ev)
+    dataset._lgcn_next_epoch = (u, p, n, ev)       # kept on the dataset itself (an id()-keyed table could hand a recycled id another dataset's epoch)
 
 
 def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=None):
@@ -73,8 +71,9 @@ def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=N
     prefetch = bool(world.config.get('prefetch_epoch', 0)) and world.device.type == 'cuda'
 
     with timer(name="Sample"):
-        if prefetch and id(dataset) in _NEXT_EPOCH:
-            users, posItems, negItems, ev = _NEXT_EPOCH.pop(id(dataset))
+        if prefetch and getattr(dataset, '_lgcn_next_epoch', None) is not None:
+            users, posItems, negItems, ev = dataset._lgcn_next_epoch
+            dataset._lgcn_next_epoch = None
             torch.cuda.current_stream().wait_event(ev)
         else:
             users, posItems, negItems = sample_epoch_to_device(dataset, world.device)
