@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
     ap.add_argument("--spmm_only", action="store_true", help="only the dominant-kernel loop (profiling helper)")
-    ap.add_argument("--spmm_reps", type=int, default=100)
+    ap.add_argument("--spmm_reps", type=int, default=2000, help="launches of the dominant kernel timed live for the roofline object (2000 x ~27 us: a 50 ms average)")
     ap.add_argument("--dp_reduce", default="rows", choices=["rows", "dense"],
                     help="data-parallel gradient exchange: all-gather of gradient rows (default) or dense all-reduce")
     ap.add_argument("--dp_shard", default="batch", choices=["batch", "rows"],
@@ -284,7 +284,6 @@ def main():
     # same workload with the other activation storage type -- so that the headline's K steps run on a GPU that is
     # already at its working clocks (a 20-step region right after set-up measured 4-5 % under steady state).
     reps = a.spmm_reps if a.workload != "synthetic-10m" else 5
-    t_spmm = spmm_kernel_time(reps)
     secondary = None
     if rank == 0 and not use_dp and not a.no_secondary and a.workload != "synthetic-10m":
         other = "bf16" if a.act_dtype == "fp32" else "fp32"
@@ -299,6 +298,7 @@ def main():
         torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
         secondary = (other, a.steps / dt2)
         del model2
+    t_spmm = spmm_kernel_time(reps)      # ~3 ms of back-to-back launches, directly ahead of the warm-up steps
 
     run(0, a.warmup)
     progress(f"timed region ({a.steps} steps)")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # run 37: the driver-style invocation after moving the secondary measurements ahead of the headline region
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02ao
+OUT=$ROOT/gpurun_out/r02aq
 mkdir -p $OUT
 cd $ROOT
 for i in 1 2 3; do

@@ -38,6 +38,21 @@ def timed(lo, n, spin=False):
         torch.cuda.synchronize()
     return n / (time.perf_counter() - t0)
 
+def split(lo, n):
+    """host wall time of the bracket vs the GPU's own time between an event before the first launch and one after the last"""
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    run(lo, n)
+    e1.record()
+    t_enq = time.perf_counter() - t0
+    while not e1.query():
+        pass
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return {"host_us": round(t_host * 1e6, 1), "enqueue_us": round(t_enq * 1e6, 1), "gpu_us": round(e0.elapsed_time(e1) * 1e3, 1)}
+
 out = {}
 run(0, 5)
 out["cold_5_warm_20"] = timed(5, 20)
@@ -50,3 +65,5 @@ time.sleep(1.0)
 out["after_sleep_20"] = timed(25, 20)
 out["after_sleep_20b"] = timed(45, 20)
 print(json.dumps({k: round(v, 1) for k, v in out.items()}))
+run(0, 400)
+print(json.dumps({"split_20_a": split(5, 20), "split_20_b": split(25, 20), "split_400": split(45, 400), "split_20_c": split(5, 20)}))
