@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--workload", default="gowalla", choices=list(WORKLOADS))
     ap.add_argument("--act_dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--xcd_remap", type=int, default=1)
+    ap.add_argument("--dense_last", default="auto", choices=["auto", "0", "1"], help="last forward layer: on the batch rows only (0) or densely (1)")
     ap.add_argument("--row_order", default=None, choices=["natural", "rcm", "cocluster", "xcd"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
@@ -184,7 +185,7 @@ def main():
     w = pkg.world
     w.configure(["--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B), "--act_dtype", a.act_dtype,
                  "--xcd_remap", str(a.xcd_remap), "--row_order", a.row_order, "--tensorboard", "0",
-                 "--dataset", a.workload])
+                 "--dataset", a.workload, "--dense_last", a.dense_last])
     import io
     import contextlib
     t_setup = time.perf_counter()

@@ -294,9 +294,15 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     // (measured on Gowalla: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
     const int parts = (d <= 64 && K <= 20 && m_items >= 4096) ? EVAL_PARTS : 1;
     void *tmp = nullptr;
+    bool tmp_sync = false;
     if (parts > 1) {
         const size_t n = (size_t)n_eval * parts * K;
-        if (hipMallocAsync(&tmp, n * (sizeof(int32_t) + sizeof(float)), st) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: cannot allocate the partial lists"); return 4; }
+        if (hipMallocAsync(&tmp, n * (sizeof(int32_t) + sizeof(float)), st) != hipSuccess) {
+            (void)hipGetLastError();
+            tmp = nullptr;
+            if (hipMalloc(&tmp, n * (sizeof(int32_t) + sizeof(float))) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: cannot allocate the partial lists"); return 4; }
+            tmp_sync = true;       // no stream-ordered pool on this runtime: plain allocation, freed after a synchronise
+        }
         a.part_items = (int32_t *)tmp; a.part_scores = (float *)((int32_t *)tmp + n);
     }
     const dim3 grid(blocks, parts);
@@ -307,12 +313,13 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     case 64: EVAL_LAUNCH(64); break;
     case 128: EVAL_LAUNCH(128); break;
     case 256: EVAL_LAUNCH(256); break;
-    default: if (tmp) (void)hipFreeAsync(tmp, st); lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
+    default: if (tmp) { if (tmp_sync) (void)hipFree(tmp); else (void)hipFreeAsync(tmp, st); } lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
     }
 #undef EVAL_LAUNCH
     if (parts > 1) {
         hipLaunchKernelGGL(k_eval_merge, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, st, a, parts);
-        (void)hipFreeAsync(tmp, st);
+        if (tmp_sync) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
+        else (void)hipFreeAsync(tmp, st);
     }
     if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_topk: launch failed"); return 10; }
     return 0;
