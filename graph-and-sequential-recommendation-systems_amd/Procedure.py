@@ -53,7 +53,7 @@ def _prefetch_next_epoch(dataset):
     """Sample + shuffle + upload the NEXT epoch on a side stream while the GPU still runs this one.
     The sampler / shuffle streams do not depend on training, so the triplets are the same ones the
     reference would draw at the start of the next epoch -- provided nothing else consumes the two
-    RNG streams in between (hence opt-in)."""
+    RNG streams in between (--prefetch_epoch 0 restores the strict order)."""
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         u, p, n = sample_epoch_to_device(dataset, world.device)
@@ -68,7 +68,7 @@ def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=N
     Recmodel.train()
     bpr = loss_class
     B = world.config['bpr_batch_size']
-    prefetch = bool(world.config.get('prefetch_epoch', 0)) and world.device.type == 'cuda'
+    prefetch = bool(world.config.get('prefetch_epoch', 1)) and world.device.type == 'cuda'
 
     with timer(name="Sample"):
         if prefetch and getattr(dataset, '_lgcn_next_epoch', None) is not None:
