@@ -731,6 +731,18 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
     }
 }
 
+// bf16 copy of the parameter table: with bf16 activation storage (K >= 2) layer 1 gathers THIS instead of the fp32
+// rows -- every SpMM input is then a 2-byte table.  Made at the start of a training call and kept current by the
+// Adam epilogue (SpmmArgs::Pb) inside a multi-step call; evaluation (lgcn_propagate_mean) makes its own.
+__global__ void __launch_bounds__(256) k_to_bf16(const float *src, bf16_t *dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        store4(dst + i * 4, load4(src + i * 4));
+}
+static void launch_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t st) {
+    const int64_t n4 = n / 4, blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, src, dst, n4);
+}
+
 // ---------------------------------------------------------------------------------
 // BPR on the batch.
 //
@@ -1382,6 +1394,12 @@ extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, 
     m.X0 = E0; m.K = K; m.out = out; m.n4 = N * d / 4;
     const size_t stride = (size_t)N * d * esize(act_dtype);
     const void *prev = E0; int prev_dtype = LGCN_F32;
+    if (act_dtype == LGCN_BF16 && K >= 2) {
+        // the same rule as the training step: with bf16 activation storage layer 1 reads bf16(E0).  `out` is free until
+        // the last layer writes it (K >= 2): its memory holds the 2-byte copy meanwhile
+        launch_to_bf16(E0, (bf16_t *)out, N * d, st);
+        prev = out; prev_dtype = LGCN_BF16;
+    }
     for (int k = 1; k <= K; k++) {
         const bool last = (k == K);
         void *y = last ? (void *)out : (void *)((char *)work + (size_t)(k - 1) * stride);
@@ -1421,6 +1439,15 @@ struct lgcn_ctx {
     void *act[LGCN_MAX_LAYERS + 1];   // act[k] = X_k storage for k = 1..K-1 (K with dense_last; also reused for H)
     int fwd_layers;               // dense forward layers per step: K-1, or K with dense_last
     float *g32;                   // [N,d] fp32 copy of the step's flagged gradient rows (library-owned; k_g32)
+    bf16_t *e0b;                  // [N,d] bf16 copy of E0 (library-owned; bf16 activation storage with K >= 2 only)
+    bool e0b_fresh;               // e0b == bf16(E0) right now (set by the Adam epilogue inside a multi-step call)
+    bool in_loop;                 // inside lgcn_train_epoch / lgcn_train_epoch_dp: the Adam epilogue keeps e0b current
+};
+// a multi-step call: nobody but this library touches E0 between its steps
+struct LoopScope {
+    lgcn_ctx *x;
+    explicit LoopScope(lgcn_ctx *x_) : x(x_) { x->in_loop = true; x->e0b_fresh = false; }
+    ~LoopScope() { x->in_loop = false; x->e0b_fresh = false; }
 };
 
 extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
@@ -1443,18 +1470,26 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     x->fwd_layers = c.dense_last ? c.K : c.K - 1;
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
-    x->g32 = nullptr;
+    x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
-    if (hipMalloc((void **)&x->g32, gbytes) != hipSuccess || hipMemset(x->g32, 0, gbytes) != hipSuccess) {
+    bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
+    if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
+    if (!ok) {
         if (x->g32) (void)hipFree(x->g32);
+        if (x->e0b) (void)hipFree(x->e0b);
         delete x;
-        lgcn_set_error("lgcn_ctx_create: cannot allocate the fp32 gradient-row table (N*d*4 bytes)");
+        lgcn_set_error("lgcn_ctx_create: cannot allocate the library-owned tables (N*d*4 bytes fp32 gradient rows, N*d*2 bf16 parameters)");
         return 4;
     }
     *out = x;
     return 0;
 }
-extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) { if (ctx) { if (ctx->g32) (void)hipFree(ctx->g32); delete ctx; } }
+extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->g32) (void)hipFree(ctx->g32);
+    if (ctx->e0b) (void)hipFree(ctx->e0b);
+    delete ctx;
+}
 extern "C" int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx) { return ctx ? ctx->step : -1; }
 extern "C" void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t s) { if (ctx) ctx->step = s; }
 extern "C" void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr) { if (ctx) ctx->c.lr = lr; }
@@ -1471,6 +1506,12 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     const void *prev = c.E0; int prev_dt = LGCN_F32;
+    if (x->e0b && x->fwd_layers >= 1) {                 // bf16 activation storage: layer 1 gathers bf16(E0)
+        if (!x->in_loop) x->e0b_fresh = false;          // a single-step call: E0 may have been written by anybody since
+        if (!x->e0b_fresh) launch_to_bf16(c.E0, x->e0b, x->N * c.d, st);
+        x->e0b_fresh = true;
+        prev = x->e0b; prev_dt = LGCN_BF16;
+    }
     for (int k = 1; k <= x->fwd_layers; k++) {
         SpmmArgs a = base_spmm(x);
         a.X = prev; a.Y = x->act[k];
@@ -1559,6 +1600,10 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
         const double bc1 = 1.0 - pow(c.beta1, (double)x->step);
         const double bc2 = 1.0 - pow(c.beta2, (double)x->step);
         a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
+        // inside a multi-step call on replicated tables the epilogue keeps the bf16 copy of E0 current (row-sharded steps
+        // update only the owned rows and convert again after the exchange)
+        a.Pb = (x->e0b && x->in_loop && fused_finish) ? x->e0b : nullptr;
+        x->e0b_fresh = a.Pb != nullptr;
         a.step_size = (float)(c.lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
         a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
         if (!first && fused_finish) {       // K >= 2: this launch also cleans the workspace and reduces the loss
@@ -1614,6 +1659,8 @@ extern "C" int lgcn_train_step(lgcn_ctx *x, const int32_t *users, const int32_t 
 extern "C" int lgcn_train_epoch(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
                                 int64_t T, int32_t B, float *loss_out, void *stream) {
     if (T <= 0) return 0;
+    if (!x) { lgcn_set_error("train epoch: null context"); return 3; }
+    LoopScope scope(x);
     int64_t i = 0;
     for (int64_t t = 0; t < T; t += B, i++) {
         const int32_t b = (int32_t)((T - t) < B ? (T - t) : B);
@@ -1694,8 +1741,10 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     case LGCN_RS_FWD: {                               // X_k[owned] = (A X_{k-1})[owned], k = 1..K-1
         if (k < 1 || k > x->fwd_layers) { lgcn_set_error("lgcn_rs_phase: forward layer out of range"); return 3; }
         SpmmArgs a = base_spmm(x);
-        a.X = k == 1 ? (const void *)c.E0 : x->act[k - 1]; a.Y = x->act[k];
-        rc = launch_spmm<0>(a, c.d, k == 1 ? LGCN_F32 : c.act_dtype, c.act_dtype, st);
+        const bool shadow = k == 1 && x->e0b != nullptr;        // bf16 activation storage: layer 1 gathers bf16(E0), converted after every exchange
+        if (shadow) { launch_to_bf16(c.E0, x->e0b, x->N * c.d, st); x->e0b_fresh = false; }
+        a.X = k == 1 ? (shadow ? (const void *)x->e0b : (const void *)c.E0) : x->act[k - 1]; a.Y = x->act[k];
+        rc = launch_spmm<0>(a, c.d, k == 1 && !shadow ? LGCN_F32 : c.act_dtype, c.act_dtype, st);
         break;
     }
     case LGCN_RS_BPR: {                               // this rank's batch shard -> cfg.contrib
@@ -1773,6 +1822,7 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
     if (!api) return 12;
     hipStream_t st = (hipStream_t)stream;
     const int world = dp->world, rank = dp->rank;
+    LoopScope scope(x);
     int64_t i = 0;
     for (int64_t t = 0; t < T; t += B_global, i++) {
         const int32_t b = (int32_t)((T - t) < B_global ? (T - t) : B_global);
