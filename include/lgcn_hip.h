@@ -175,8 +175,9 @@ typedef struct {
                                    when the batch rows together hold more non-zeros than the graph (hub-heavy data) */
 } lgcn_train_config;
 
-/* Besides the caller's workspace the context owns ONE device allocation of N*d*4 bytes (fp32 copy of the step's
- * sparse gradient rows), made here with hipMalloc and released by lgcn_ctx_destroy; returns 4 if it cannot be had. */
+/* Besides the caller's workspace the context owns device allocations made here with hipMalloc and released by
+ * lgcn_ctx_destroy: N*d*4 bytes (fp32 copy of the step's sparse gradient rows) and, with act_dtype = LGCN_BF16 and
+ * K >= 2, N*d*2 bytes (bf16 copy of E0: the input of layer 1 in that mode).  Returns 4 if they cannot be had. */
 int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out);
 void lgcn_ctx_destroy(lgcn_ctx *ctx);
 /* optimizer step counter (torch Adam state['step']) for checkpoint/resume */
