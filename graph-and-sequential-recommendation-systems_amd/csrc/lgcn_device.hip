@@ -357,7 +357,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
             //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
-            //  k_bpr_loss of the next step zeroes the stale one with plain stores)
+            //  k_triplet of the next step zeroes the stale one with plain stores)
             i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
 #pragma unroll
             for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
@@ -756,7 +756,7 @@ static void launch_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t
 //   (Round 1/2 history: one workgroup per SLOT + a loss launch = 24.6K waves of which 18K ended after reading
 //   two indices; the launch skeleton alone -- ids, indptr, nothing else -- measured 7.3 of its 16.7 us, and
 //   the slot rows made a round trip through HBM to the 6.7 us loss launch.)
-// k_rows_dense + k_bpr_loss: the same when the last layer was propagated densely (cfg.dense_last).
+// k_triplet_dense: the same when the last layer was propagated densely (cfg.dense_last).
 // ---------------------------------------------------------------------------------
 struct BprArgs {
     const int32_t *indptr; const int32_t *indices; const float *vals;
@@ -767,7 +767,7 @@ struct BprArgs {
     int32_t shard;        // row stride of the contrib block (>= B_local)
     float inv_B;          // 1 / global batch
     float lam;            // decay / global batch
-    float *ebuf;          // [3, B_local, D] propagated rows of the slots
+    float *ebuf;          // (unused since run 56: the slot rows stay in registers / LDS; the configuration field remains)
     long long *G64;       // if non-null: atomics
     uint32_t *bitmap;
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
@@ -833,32 +833,6 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
         }
         if (a.G64 && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
     }
-}
-
-// the same from the slot rows k_rows_dense left in ebuf
-template <int D>
-__device__ __forceinline__ void triplet_loss(const BprArgs &a, int b, int l) {
-    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
-    float u[CPL], p[CPL], n[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; j++) {
-        u[j] = a.ebuf[((int64_t)0 * a.B_local + b) * D + j * LPT + l];
-        p[j] = a.ebuf[((int64_t)1 * a.B_local + b) * D + j * LPT + l];
-        n[j] = a.ebuf[((int64_t)2 * a.B_local + b) * D + j * LPT + l];
-    }
-    triplet_loss_regs<D>(a, b, l, u, p, n);
-}
-
-// the loss launch of the dense_last form (k_triplet does the same inside the triplet's own workgroup)
-template <int D>
-__global__ void __launch_bounds__(256) k_bpr_loss(BprArgs a) {
-    constexpr int LPT = D < 64 ? D : 64, TPB = 256 / LPT;     // lanes per triplet, triplets per workgroup
-    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
-        a.stale_bitmap[i] = 0u;
-    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
-    if (b >= a.B_local) return;                 // whole lane groups leave together
-    triplet_loss<D>(a, b, l);
 }
 
 #ifndef TRIPLET_MIN_WAVES
@@ -973,23 +947,35 @@ __global__ void __launch_bounds__(256, sizeof(TI) == 4 ? 8 : TRIPLET_MIN_WAVES) 
     else triplet_body<D, TI, TI>(a, a.Xl[a.K - 1], stage, part_lds, base_lds);
 }
 
-// Slot rows when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row
-// reads.  On graphs whose positives concentrate on hub items (a popularity-weighted mean item degree in the
-// thousands: the synthetic Yelp / Amazon shapes) the slots together hold several times the graph's non-zeros
-// -- one more dense SpMM is then far cheaper than per-slot gathers (236 -> ~50 us at B = 8192).
+// The same when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row reads per slot,
+// so one lane group (lane = column mod 64) does a whole triplet: 3 x (K+1) coalesced row reads, loss, atomics.  On graphs
+// whose positives concentrate on hub items (a popularity-weighted mean item degree in the thousands: the synthetic Yelp /
+// Amazon shapes) the slots together hold several times the graph's non-zeros -- one more dense SpMM is then far cheaper
+// than per-slot gathers (236 -> ~50 us at B = 8192).  (Until run 56 this was two launches with the slot rows in HBM between.)
 template <int D, typename TI>
-__global__ void __launch_bounds__(256) k_rows_dense(BprArgs a) {
-    constexpr int LPR = D / 4, SPB = 256 / LPR;
-    const int64_t s = (int64_t)blockIdx.x * SPB + threadIdx.x / LPR;
-    const int l = threadIdx.x % LPR;
-    if (s >= (int64_t)3 * a.B_local) return;
-    const int c = (int)(s / a.B_local), b = (int)(s % a.B_local);
-    int64_t row = c == 0 ? (int64_t)a.users[b] : (int64_t)(c == 1 ? a.pos[b] : a.neg[b]) + a.n_users;
-    if (triplet_bad(a, b)) { if (l == 0) atomicExch(a.err, 1); row = 0; }
-    const int64_t off = row * D + l * 4;
-    f32x4 acc = load4(a.X0 + off);
-    for (int k = 1; k <= a.K; k++) acc += load4((const TI *)a.Xl[k] + off);
-    store4(a.ebuf + s * D + l * 4, acc / (float)(a.K + 1));
+__global__ void __launch_bounds__(256) k_triplet_dense(BprArgs a) {
+    constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT, TPB = 256 / LPT;     // lanes per triplet, triplets per workgroup
+    // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
+        a.stale_bitmap[i] = 0u;
+    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
+    if (b >= a.B_local) return;                 // whole lane groups leave together
+    const bool bad = triplet_bad(a, b);
+    if (bad && l == 0) atomicExch(a.err, 1);
+    const int64_t rows[3] = {bad ? 0 : (int64_t)a.users[b], bad ? 0 : (int64_t)a.pos[b] + a.n_users, bad ? 0 : (int64_t)a.neg[b] + a.n_users};
+    const float div = (float)(a.K + 1);
+    float e[3][CPT];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int64_t o = rows[c] * D + j * LPT + l;
+            float s = a.X0[o];
+            for (int k = 1; k <= a.K; k++) s += (float)((const TI *)a.Xl[k])[o];
+            e[c][j] = s / div;
+        }
+    }
+    triplet_loss_regs<D>(a, b, l, e[0], e[1], e[2]);
 }
 
 // slot -> destination row of the global batch (-1: the slot's triplet has a bad id)
@@ -1032,7 +1018,7 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
 }
 
 // Gs rows of the batch, once per step: G32[row] = (float)(G64[row] * 2^-50) / (K+1) for every slot's row, after
-// ALL contributions are in (k_bpr_loss / k_scatter / the all-reduce).  Slots that share a row write the same
+// ALL contributions are in (k_triplet / k_scatter / the all-reduce).  Slots that share a row write the same
 // bytes.  The first backward layer gathers these 4-byte rows (and every Horner epilogue adds them) instead of
 // converting the fixed-point rows per gathered copy.
 template <int D>
@@ -1540,17 +1526,16 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.ebuf = c.ebuf;
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
-        // two steps ago still has to be cleared (k_triplet / k_bpr_loss does it on the other ranks)
+        // two steps ago still has to be cleared (k_triplet / k_triplet_dense does it on the other ranks)
         HIP_OK(hipMemsetAsync(a.stale_bitmap, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
         return 0;
     }
     DISPATCH_D(c.d, {
         if (c.dense_last) {
-            const unsigned gd = (unsigned)(((int64_t)3 * B_local + 256 / (D / 4) - 1) / (256 / (D / 4)));
-            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_rows_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_rows_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
             const int tpb = 256 / (D < 64 ? D : 64);
-            hipLaunchKernelGGL((k_bpr_loss<D>), dim3((B_local + tpb - 1) / tpb), dim3(256), 0, st, a);
+            const unsigned gd = (unsigned)((B_local + tpb - 1) / tpb);
+            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_triplet_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
         } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float>), dim3(B_local), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_triplet<D, bf16_t>), dim3(B_local), dim3(256), 0, st, a);
     });

@@ -162,7 +162,7 @@ typedef struct {
     int64_t *G64;               /* [N,d] fixed-point (2^50) accumulator of the sparse-row gradient */
     uint32_t *bitmap;           /* [2*ceil(N/32)] rows of G64 that are non-zero (two, used alternately) */
     float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
-    float *ebuf;                /* [3*max_batch*d] propagated rows of the batch slots */
+    float *ebuf;                /* [3*max_batch*d] workspace, non-NULL (no longer written: the batch slot rows stay on chip) */
     float *contrib;             /* [3*max_batch*d + 2*max_batch] (data-parallel exchange buffer) or NULL */
     int32_t *err;               /* [1] device error flag */
     int32_t max_batch;
