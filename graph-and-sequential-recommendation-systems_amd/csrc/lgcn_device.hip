@@ -384,28 +384,36 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
 // partials, then an xor-shuffle tree): loss_out = {bpr + decay*reg, bpr, reg}   (model.py:168-173)
 __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float *gathered, int B, int shard,
                                                  int D, float decay, float *loss_out, int lane) {
-    // Every lane adds its terms b = lane, lane + 64, ... in that order (the order is part of the result); the loads
-    // of 16 of them are issued together -- one wave walks the whole global batch, and with one load per round trip a
-    // 16 384-triplet batch (8 ranks) took 100 us and held the +Adam launch back (38 -> 108 us).
+    // Every lane adds its terms b = lane, lane + 64, ... in that order (the order is part of the result).
     float fl = 0.f, fr = 0.f;
-    constexpr int UL = 16;
-    const int64_t blk = (int64_t)3 * shard * D + 2 * shard;
-    for (int b0 = 0; b0 < B; b0 += 64 * UL) {
-        float tl[UL], tr[UL];
+    if (!gathered) {
+        // one GPU: the plain loop (deeper explicit batches made the launch it rides in slower: 3214-3278 steps/s at
+        // B = 8192 for 32 ... 4 loads in flight, 3296 for this form)
+#pragma unroll 8
+        for (int b = lane; b < B; b += 64) { fl += terms[b]; fr += terms[B + b]; }
+    } else {
+        // data parallel: the terms of the GLOBAL batch lie in the ranks' blocks.  16 loads in flight: with one load per
+        // round trip a 16 384-triplet batch (8 ranks) took 100 us and held the +Adam launch back (38 -> 108 us).
+        // (r, i) = (block, position in it) of this lane's next term, advanced without divisions.
+        constexpr int UL = 16;
+        const int64_t blk = (int64_t)3 * shard * D + 2 * shard;
+        int r = lane / shard, i = lane % shard;
+        for (int b0 = 0; b0 < B; b0 += 64 * UL) {
+            float tl[UL], tr[UL];
 #pragma unroll
-        for (int u = 0; u < UL; u++) {
-            const int b = b0 + u * 64 + lane, bb = b < B ? b : 0;          // past the end: a valid address, weight 0
-            if (gathered) {
-                const float *t = gathered + (bb / shard) * blk + (int64_t)3 * shard * D;
-                tl[u] = t[bb % shard]; tr[u] = t[shard + bb % shard];
-            } else {
-                tl[u] = terms[bb]; tr[u] = terms[B + bb];
+            for (int u = 0; u < UL; u++) {
+                const bool in = b0 + u * 64 + lane < B;
+                const float *t = gathered + (in ? r : 0) * blk + (int64_t)3 * shard * D;      // past the end: a valid address, weight 0
+                const int ii = in ? i : 0;
+                tl[u] = t[ii]; tr[u] = t[shard + ii];
+                i += 64;
+                while (i >= shard) { i -= shard; r++; }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < UL; u++) {
-            const bool in = b0 + u * 64 + lane < B;
-            fl += in ? tl[u] : 0.f; fr += in ? tr[u] : 0.f;
+            for (int u = 0; u < UL; u++) {
+                const bool in = b0 + u * 64 + lane < B;
+                fl += in ? tl[u] : 0.f; fr += in ? tr[u] : 0.f;
+            }
         }
     }
 #pragma unroll
