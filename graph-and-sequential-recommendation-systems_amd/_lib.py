@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -59,6 +59,7 @@ SIGNATURES = {
     "lgcn_ctx_get_step": (C.c_int64, [_vp]),
     "lgcn_ctx_set_step": (None, [_vp, C.c_int64]),
     "lgcn_ctx_set_lr": (None, [_vp, C.c_double]),
+    "lgcn_ctx_set_dp_local": (C.c_int, [_vp, C.c_int]),
     "lgcn_train_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_train_epoch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
     "lgcn_train_step_dp_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),

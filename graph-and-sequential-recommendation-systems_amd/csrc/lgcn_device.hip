@@ -779,7 +779,8 @@ struct BprArgs {
     long long *G64;       // if non-null: atomics
     uint32_t *bitmap;
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
-    float *contrib;       // else: [3*shard*D | shard | shard]
+    float *contrib;       // exchange block [3*shard*D | shard | shard] (data parallel)
+    int32_t exchange;     // write the gradient rows and loss terms to `contrib` (instead of / besides the atomics)
     float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
     int32_t terms_off, terms_stride;
     int32_t *err;
@@ -820,26 +821,24 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
     const float x = ps - ns;
     const float gb = tbad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
     if (l == 0) {
-        float *lt = a.G64 ? a.terms + a.terms_off : a.contrib + (int64_t)3 * a.shard * D;
-        const int stride = a.G64 ? a.terms_stride : a.shard;
+        float *lt = a.exchange ? a.contrib + (int64_t)3 * a.shard * D : a.terms + a.terms_off;
+        const int stride = a.exchange ? a.shard : a.terms_stride;
         lt[b] = tbad ? 0.f : logsigmoid_f(x);
         lt[stride + b] = tbad ? 0.f : rr;
     }
-    if (a.G64 && tbad) return;
+    if (tbad && !a.exchange) return;
     const int64_t rows[3] = {(int64_t)a.users[b], (int64_t)a.pos[b] + a.n_users, (int64_t)a.neg[b] + a.n_users};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
             float g = c == 0 ? gb * (p[j] - n[j]) + a.lam * u[j] : (c == 1 ? gb * u[j] + a.lam * p[j] : (-gb) * u[j] + a.lam * n[j]);
-            if (a.G64) {
+            if (a.G64 && !tbad)
                 atomicAdd((unsigned long long *)(a.G64 + rows[c] * D + j * LPT + l),
                           (unsigned long long)__double2ll_rn((double)g * FIXED_SCALE));
-            } else {
-                a.contrib[((int64_t)c * a.shard + b) * D + j * LPT + l] = tbad ? 0.f : g;
-            }
+            if (a.exchange) a.contrib[((int64_t)c * a.shard + b) * D + j * LPT + l] = tbad ? 0.f : g;
         }
-        if (a.G64 && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
+        if (a.G64 && !tbad && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
     }
 }
 
@@ -1000,6 +999,7 @@ struct SlotArgs {
     long long *G64; uint32_t *bitmap;
     float *G32; float div;                                 // k_g32: fp32 copy of the flagged rows, K+1
     const float *gathered; int32_t shard; int32_t world;   // DP scatter
+    int32_t skip_rank;                                     // DP scatter: this rank's own block is in G64 already (-1: none)
     const float *terms; float *loss_out; float decay;
 };
 
@@ -1016,6 +1016,7 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     const int64_t row = slot_row(c, b, a.users, a.pos, a.neg, a.n_users, a.N);
     if (row < 0) return;
     const int r = b / a.shard, i = b % a.shard;
+    if (r == a.skip_rank) return;
     const int64_t blk = (int64_t)3 * a.shard * D + 2 * a.shard;
     const float *src = a.gathered + r * blk + ((int64_t)c * a.shard + i) * D;
 #pragma unroll
@@ -1436,6 +1437,8 @@ struct lgcn_ctx {
     bf16_t *e0b;                  // [N,d] bf16 copy of E0 (library-owned; bf16 activation storage with K >= 2 only)
     bool e0b_fresh;               // e0b == bf16(E0) right now (set by the Adam epilogue inside a multi-step call)
     bool in_loop;                 // inside lgcn_train_epoch / lgcn_train_epoch_dp: the Adam epilogue keeps e0b current
+    bool dp_local;                // data parallel (rows): part 1 also adds this rank's own rows into G64, part 2 scatters the others'
+    int dp_rank;                  // rank of the last part 1
 };
 // a multi-step call: nobody but this library touches E0 between its steps
 struct LoopScope {
@@ -1464,7 +1467,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     x->fwd_layers = c.dense_last ? c.K : c.K - 1;
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
-    x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false;
+    x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
@@ -1483,6 +1486,11 @@ extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
     if (ctx->g32) (void)hipFree(ctx->g32);
     if (ctx->e0b) (void)hipFree(ctx->e0b);
     delete ctx;
+}
+extern "C" int lgcn_ctx_set_dp_local(lgcn_ctx *ctx, int on) {
+    if (!ctx) { lgcn_set_error("lgcn_ctx_set_dp_local: null context"); return 3; }
+    ctx->dp_local = on != 0; ctx->dp_rank = -1;
+    return 0;
 }
 extern "C" int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx) { return ctx ? ctx->step : -1; }
 extern "C" void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t s) { if (ctx) ctx->step = s; }
@@ -1517,7 +1525,7 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
 }
 
 static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
-                   int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, hipStream_t st) {
+                   int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, bool exchange, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     BprArgs a{};
     a.indptr = c.graph->indptr; a.indices = c.graph->indices; a.vals = c.graph->vals; a.X0 = c.E0; a.K = c.K;
@@ -1529,8 +1537,8 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.inv_B = 1.0f / (float)B_global; a.lam = c.decay / (float)B_global;
     a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = c.bitmap + x->flip * x->bm_words;
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
-    a.contrib = c.contrib; a.terms = c.terms; a.err = c.err;
-    a.terms_off = atomics ? b_off : 0; a.terms_stride = B_global;
+    a.contrib = c.contrib; a.terms = c.terms; a.err = c.err; a.exchange = exchange ? 1 : 0;
+    a.terms_off = exchange ? 0 : b_off; a.terms_stride = B_global;
     a.ebuf = c.ebuf;
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
@@ -1557,7 +1565,7 @@ static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t
     s.users = users; s.pos = pos; s.neg = neg; s.B = B; s.n_users = c.n_users; s.N = x->N;
     s.G64 = (long long *)c.G64; s.G32 = x->g32; s.div = (float)(c.K + 1);
     s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
-    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay;
+    s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay; s.skip_rank = -1;
     return s;
 }
 static unsigned scatter_grid(const lgcn_ctx *x, int32_t B) {      // k_scatter: one lane group of min(d, 64) lanes per slot
@@ -1618,7 +1626,10 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
     { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     SlotArgs s = slot_args(x, users, pos, neg, B, gathered, shard, world, loss_out);
     const unsigned sgrid = slot_grid(x, B);
-    if (gathered) { DISPATCH_D(c.d, hipLaunchKernelGGL((k_scatter<D>), dim3(scatter_grid(x, B)), dim3(256), 0, st, s)); }
+    if (gathered) {
+        s.skip_rank = x->dp_local ? x->dp_rank : -1;       // part 1 already added this rank's own rows
+        DISPATCH_D(c.d, hipLaunchKernelGGL((k_scatter<D>), dim3(scatter_grid(x, B)), dim3(256), 0, st, s));
+    }
     x->step += 1;
     // Horner: h_{K-1} = Gs + A Gs (sparse input); h_{k-1} = Gs + A h_k; last one feeds Adam
     for (int k = c.K; k >= 1; k--) {
@@ -1643,7 +1654,7 @@ extern "C" int lgcn_train_step(lgcn_ctx *x, const int32_t *users, const int32_t 
     if (!loss_out) { lgcn_set_error("train step: loss_out is null"); return 3; }
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, st))) return rc;
+    if ((rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, false, st))) return rc;
     if ((rc = run_backward(x, users, pos, neg, B, nullptr, B, 1, loss_out, st))) return rc;
     HIP_OK(hipGetLastError());
     return 0;
@@ -1676,7 +1687,9 @@ extern "C" int lgcn_train_step_dp_part1(lgcn_ctx *x, const int32_t *users, const
     if (B_local < 0) B_local = 0;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, false, st))) return rc;
+    // with dp_local the rank's own rows go into G64 here (atomics) AND into the exchange block; part 2 scatters the others'
+    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, x->dp_local, true, st))) return rc;
+    x->dp_rank = rank;
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1695,7 +1708,7 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
     // this rank owns positions [b_off, b_off+B_local) of the global loss-term arrays; the rest must be zero
     HIP_OK(hipMemsetAsync(x->c.terms, 0, sizeof(float) * 2 * (size_t)B_global, st));
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, st))) return rc;
+    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st))) return rc;
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B_global; s.n_users = x->c.n_users; s.N = x->N;
     s.bitmap = x->c.bitmap + x->flip * x->bm_words;
@@ -1746,7 +1759,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
         int32_t B_local = B_global - b_off;
         if (B_local > shard) B_local = shard;
         if (B_local < 0) B_local = 0;
-        rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, false, st);
+        rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, false, true, st);
         break;
     }
     case LGCN_RS_SCATTER: {                           // all ranks' gradient rows -> G64 + row flags
@@ -1816,6 +1829,11 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
     hipStream_t st = (hipStream_t)stream;
     const int world = dp->world, rank = dp->rank;
     LoopScope scope(x);
+    struct LocalScope {         // batch-sharded rows mode: every rank adds its own rows itself, k_scatter the other ranks'
+        lgcn_ctx *x; bool was;
+        LocalScope(lgcn_ctx *x_, bool on) : x(x_), was(x_->dp_local) { x->dp_local = on; x->dp_rank = -1; }
+        ~LocalScope() { x->dp_local = was; x->dp_rank = -1; }
+    } local_scope(x, reduce == LGCN_DP_ROWS);
     int64_t i = 0;
     for (int64_t t = 0; t < T; t += B_global, i++) {
         const int32_t b = (int32_t)((T - t) < B_global ? (T - t) : B_global);

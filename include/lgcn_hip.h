@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 6
+#define LGCN_ABI_VERSION 7
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -184,6 +184,10 @@ void lgcn_ctx_destroy(lgcn_ctx *ctx);
 int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx);
 void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t step);
 void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr);
+/* Data parallel, rows mode: 1 = part 1 of a step also adds this rank's OWN gradient rows into its G64 (besides writing
+ * them to the exchange block) and part 2 scatters only the other ranks' blocks -- what lgcn_train_epoch_dp does itself;
+ * 0 (default) = part 2 scatters every block (one context may then play several ranks, as the emulation tests do). */
+int lgcn_ctx_set_dp_local(lgcn_ctx *ctx, int on);
 
 /* One full stageOne on a batch of B triplets (device int32 ids).
  * loss_out[0..2] (device) = {bpr + decay*reg, bpr, reg}.  No host sync.        */

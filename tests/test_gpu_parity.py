@@ -276,6 +276,47 @@ def test_bitwise_reproducible_and_dp_split(pkg, tiny, tmp_path):
         np.testing.assert_allclose(ld, l1, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("local", [0, 1])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_dp_rows_one_model_per_rank(pkg, tiny, tmp_path, world, local):
+    """The batch-sharded step the way the ranks really run it: W separate models (same seed), each rank's part 1 on ITS
+    model, the blocks concatenated in rank order (the all-gather), each rank's part 2 on its model.  local = 1 is what
+    lgcn_train_epoch_dp does: part 1 also adds the rank's own rows into its G64 and part 2 scatters only the others'.
+    Every model must end bit for bit where the single-GPU model ends; ragged last shard, duplicate ids across ranks."""
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(5 + world))
+    batches = [(rng.integers(0, g.n_users, b), rng.integers(0, g.m_items, b), rng.integers(0, 12, b)) for b in (64, 41, 64)]
+    ds, ref = _make_model(pkg, g, tmp_path)
+    for (u, p, n) in batches:
+        ref.fused_step(_dev(u, torch.int32), _dev(p, torch.int32), _dev(n, torch.int32))
+    want = ref._table.cpu().numpy().view(np.uint32)
+    L, lib = pkg._lib, pkg._lib.load()
+    models = [_make_model(pkg, g, tmp_path)[1] for _ in range(world)]
+    states = [m._state(max_batch=64, need_ctx=True, dp_world=world) for m in models]
+    for st in states:
+        L.check(lib.lgcn_ctx_set_dp_local(st['ctx'], local), "set_dp_local")
+    for (u, p, n) in batches:
+        u, p, n = (_dev(x, torch.int32) for x in (u, p, n))
+        B = len(u)
+        nblk = pkg.parallel.block_numel(B, world, g.d)
+        blocks = []
+        for r, st in enumerate(states):
+            L.check(lib.lgcn_train_step_dp_part1(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, r, L.current_stream()), "part1")
+            blocks.append(st['contrib'][:nblk].clone())
+        gathered = torch.cat(blocks)
+        outs = []
+        for st in states:
+            out = torch.empty(3, device=DEV)
+            L.check(lib.lgcn_train_step_dp_part2(st['ctx'], L.tp(u), L.tp(p), L.tp(n), B, world, L.tp(gathered), L.tp(out),
+                                                 L.current_stream()), "part2")
+            outs.append(out.cpu().numpy())
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    for r, m in enumerate(models):
+        assert np.array_equal(m._table.cpu().numpy().view(np.uint32), want), (world, local, r)
+        assert int(m._dev['G64'].abs().sum()) == 0
+        m.check_device_errors()
+
+
 def test_out_of_range_ids_are_flagged_not_faulting(pkg, tiny, tmp_path):
     ds, m = _make_model(pkg, tiny, tmp_path)
     before = m._table.clone()

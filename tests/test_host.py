@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(pkg._lib.SIGNATURES) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lgcn_abi_version() == 6
+    assert lib.lgcn_abi_version() == 7
     assert lib.lgcn_device_available() in (0, 1)
 
 

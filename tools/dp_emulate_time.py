@@ -28,6 +28,7 @@ for world in (1, 2, 4, 8):
         u, p, n = pkg.Procedure.sample_epoch_to_device(ds, dev)
     st = m._state(max_batch=Bg, need_ctx=True, dp_world=world)
     lib = L.load()
+    L.check(lib.lgcn_ctx_set_dp_local(st['ctx'], 1), "set_dp_local")      # as lgcn_train_epoch_dp runs it: own rows added in part 1
     blk = pkg.parallel.block_numel(Bg, world, m.latent_dim)
     gathered = torch.zeros(world * blk, dtype=torch.float32, device=dev)
     loss = torch.empty(3, dtype=torch.float32, device=dev)
