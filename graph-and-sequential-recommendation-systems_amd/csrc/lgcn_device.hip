@@ -781,6 +781,7 @@ struct BprArgs {
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
     float *contrib;       // exchange block [3*shard*D | shard | shard] (data parallel)
     int32_t exchange;     // write the gradient rows and loss terms to `contrib` (instead of / besides the atomics)
+    const float *Xhub; int32_t hub_nnz;     // rows with more than hub_nnz non-zeros: X_K[row] is read from Xhub (0: none)
     float *terms;         // atomics mode: [2*terms_stride] (loss terms | reg terms), this launch at terms_off
     int32_t terms_off, terms_stride;
     int32_t *err;
@@ -842,6 +843,9 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
     }
 }
 
+#ifndef TRIPLET_HUB_NNZ
+#define TRIPLET_HUB_NNZ 32768  /* rows longer than this get their last-layer row from the hub plan (whole chip) instead of one workgroup */
+#endif
 #ifndef TRIPLET_MIN_WAVES
 #define TRIPLET_MIN_WAVES 4    /* bf16 tables: a 64-VGPR cap spills (7290 vs 7610 steps/s); fp32 tables fit 64 without (8 workgroups per CU, +0.4 %) */
 #endif
@@ -913,7 +917,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {                       // (not unrolled: three inlined copies of the gather loop cost 20 VGPRs)
         const int stc = c == 0 ? st0 : (c == 1 ? st1 : st2), nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
-        const int u0 = (w - c + 4) & 3, units = (nc + UN - 1) / UN;
+        const int u0 = (w - c + 4) & 3, units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
         if (u0 < units) {
             const typename G::Acc x = units_gather<D, TG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
             if (lane < LPR) storev<C>(&part[c][w][lane * C], x);
@@ -928,11 +932,14 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
     float e[3][CPT];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const int units = ((c == 0 ? n0 : (c == 1 ? n1 : n2)) + UN - 1) / UN;
+        const int nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
+        const bool hub = a.hub_nnz && nc > a.hub_nnz;
+        const int units = hub ? 0 : (nc + UN - 1) / UN;
+        const int64_t rowc = c == 0 ? row0 : (c == 1 ? row1 : row2);
 #pragma unroll
         for (int j = 0; j < CPT; j++) {
             const int col = j * LPT + lane;
-            float xk = 0.f;
+            float xk = hub ? a.Xhub[rowc * D + col] : 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++) if (i < units) xk += part[c][(c + i) & 3][col];     // unit 0's wave first
             e[c][j] = (base[c][col] + xk) / div;
@@ -1437,6 +1444,8 @@ struct lgcn_ctx {
     bf16_t *e0b;                  // [N,d] bf16 copy of E0 (library-owned; bf16 activation storage with K >= 2 only)
     bool e0b_fresh;               // e0b == bf16(E0) right now (set by the Adam epilogue inside a multi-step call)
     bool in_loop;                 // inside lgcn_train_epoch / lgcn_train_epoch_dp: the Adam epilogue keeps e0b current
+    lgcn_graph *hub_graph;        // plan over the rows with more than hub_nnz non-zeros (or NULL): their last-layer rows are
+    int32_t hub_nnz;              //   computed by k_spmm into g32 before k_triplet instead of by the one workgroup of a triplet
     bool dp_local;                // data parallel (rows): part 1 also adds this rank's own rows into G64, part 2 scatters the others'
     int dp_rank;                  // rank of the last part 1
 };
@@ -1468,12 +1477,35 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
     x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
+    x->hub_graph = nullptr; x->hub_nnz = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
+    if (ok && !c.dense_last) {
+        // Rows too long for one workgroup (a 800 000-neighbour item of the 10M x 1M graph kept ONE k_triplet workgroup busy
+        // for 37 ms, several times per batch): a plan over just those rows; k_spmm computes their last-layer rows for
+        // the whole chip to share, once per step, before k_triplet.
+        int32_t thr = TRIPLET_HUB_NNZ;
+        if (const char *e = getenv("LGCN_TRIPLET_HUB_NNZ")) thr = atoi(e);
+        if (thr > 0) {
+            std::vector<int32_t> ip((size_t)x->N + 1), hubs;
+            ok = hipMemcpy(ip.data(), c.graph->indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost) == hipSuccess;
+            for (int64_t r = 0; ok && r < x->N; r++) if (ip[(size_t)r + 1] - ip[(size_t)r] > thr) hubs.push_back((int32_t)r);
+            if (ok && !hubs.empty()) {
+                int32_t *dh = nullptr;
+                ok = hipMalloc((void **)&dh, sizeof(int32_t) * hubs.size()) == hipSuccess &&
+                     hipMemcpy(dh, hubs.data(), sizeof(int32_t) * hubs.size(), hipMemcpyHostToDevice) == hipSuccess;
+                if (ok) ok = lgcn_graph_create(c.graph->indptr, c.graph->indices, c.graph->vals, x->N, c.graph->nnz, c.d, dh,
+                                               (int64_t)hubs.size(), nullptr, &x->hub_graph) == 0;
+                if (dh) (void)hipFree(dh);
+                x->hub_nnz = thr;
+            }
+        }
+    }
     if (!ok) {
         if (x->g32) (void)hipFree(x->g32);
         if (x->e0b) (void)hipFree(x->e0b);
+        if (x->hub_graph) lgcn_graph_destroy(x->hub_graph);
         delete x;
         lgcn_set_error("lgcn_ctx_create: cannot allocate the library-owned tables (N*d*4 bytes fp32 gradient rows, N*d*2 bf16 parameters)");
         return 4;
@@ -1485,6 +1517,7 @@ extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->g32) (void)hipFree(ctx->g32);
     if (ctx->e0b) (void)hipFree(ctx->e0b);
+    if (ctx->hub_graph) lgcn_graph_destroy(ctx->hub_graph);
     delete ctx;
 }
 extern "C" int lgcn_ctx_set_dp_local(lgcn_ctx *ctx, int on) {
@@ -1540,6 +1573,15 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err; a.exchange = exchange ? 1 : 0;
     a.terms_off = exchange ? 0 : b_off; a.terms_stride = B_global;
     a.ebuf = c.ebuf;
+    if (x->hub_graph && !c.dense_last && B_local > 0) {
+        // last layer of the hub rows, X_K[hub] = (A_hat X_{K-1})[hub] in fp32, into the library's [N,d] table (free until k_g32)
+        { int rc0 = graph_acquire(x->hub_graph, st); if (rc0) return rc0; }
+        SpmmArgs h = graph_spmm(x->hub_graph);
+        h.X = c.K == 1 ? (const void *)c.E0 : x->act[c.K - 1]; h.Y = x->g32; h.remap = c.xcd_remap;
+        int rc = launch_spmm<0>(h, c.d, c.K == 1 ? LGCN_F32 : c.act_dtype, LGCN_F32, st);
+        if (rc) return rc;
+        a.Xhub = x->g32; a.hub_nnz = x->hub_nnz;
+    }
     if (B_local <= 0) {
         // a rank whose shard of a short last batch is empty launches nothing, but the row bitmap of
         // two steps ago still has to be cleared (k_triplet / k_triplet_dense does it on the other ranks)

@@ -503,11 +503,15 @@ def test_fused_steps_other_dims_vs_oracle(pkg, oracle, tmp_path, d, K, act):
     m.check_device_errors()
 
 
+@pytest.mark.parametrize("hub", [0, 200])
 @pytest.mark.parametrize("d,K,act", [(64, 3, "fp32"), (32, 1, "fp32"), (256, 2, "fp32"), (128, 3, "bf16")])
-def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act):
+def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, monkeypatch, d, K, act, hub):
     """k_triplet cuts a slot row into units of 128 non-zeros dealt to the workgroup's four waves: batches whose user /
     positive / negative rows sit exactly on and around every unit and wave-wrap boundary (1 ... 1300 non-zeros,
     item hubs of 350 / 700 / 1400), duplicates of the same hub in one batch, vs the oracle's stageOne."""
+    # hub = 200: rows with more than 200 non-zeros take the hub plan (k_spmm computes their last-layer rows for k_triplet to
+    # read) -- the production threshold is 32 768 and only the 10M x 1M graph crosses it
+    monkeypatch.setenv("LGCN_TRIPLET_HUB_NNZ", str(hub))
     lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640, 1025, 1300]
     n_users = m_items = 1400
     path = os.path.join(str(tmp_path), f"units{d}")
