@@ -844,7 +844,11 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
 }
 
 #ifndef TRIPLET_HUB_NNZ
-#define TRIPLET_HUB_NNZ 32768  /* rows longer than this get their last-layer row from the hub plan (whole chip) instead of one workgroup */
+#define TRIPLET_HUB_NNZ 131072  /* rows longer than this get their last-layer row from the hub plan (whole chip) instead of one workgroup
+                                  (10M x 1M graph, ms per step: off 264, 8192: 242, 32768: 236, 65536: 239, 131072: 228, 262144: 231, 524288: 244) */
+#endif
+#ifndef TRIPLET_HUB_CHUNK
+#define TRIPLET_HUB_CHUNK 2048   /* non-zeros per chunk of the hub plan's rows */
 #endif
 #ifndef TRIPLET_MIN_WAVES
 #define TRIPLET_MIN_WAVES 4    /* bf16 tables: a 64-VGPR cap spills (7290 vs 7610 steps/s); fp32 tables fit 64 without (8 workgroups per CU, +0.4 %) */
@@ -1191,9 +1195,19 @@ __global__ void __launch_bounds__(256) k_pack_stream(const int4 *items, int64_t 
     }
 }
 
+static int graph_create_impl(const int32_t *indptr, const int32_t *indices, const float *vals,
+                             int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
+                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, lgcn_graph **out);
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                                  int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
                                  int64_t n_order, const int64_t *xcd_start, lgcn_graph **out) {
+    return graph_create_impl(indptr, indices, vals, n_rows, nnz, d_max, row_order, n_order, xcd_start, LONG_CH, out);
+}
+// long_ch: non-zeros per chunk of a split row (LONG_CH for the propagation plans; the hub plan of k_triplet, whose rows
+// have 10^4 .. 10^6 non-zeros, takes longer chunks so that a row's last arriver has hundreds, not thousands, of partials to add)
+static int graph_create_impl(const int32_t *indptr, const int32_t *indices, const float *vals,
+                             int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
+                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, lgcn_graph **out) {
     if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
         n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
     if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
@@ -1267,10 +1281,10 @@ extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, 
             const int32_t r = row_order ? ord[(size_t)p] : (int32_t)p;
             const int32_t s0 = ip[(size_t)r], deg = ip[(size_t)r + 1] - s0;
             if (deg > LONG_T) {
-                const int nch = (deg + LONG_CH - 1) / LONG_CH;
+                const int nch = (deg + long_ch - 1) / long_ch;
                 const int32_t lb = (int32_t)n_pk;
                 for (int k = 0; k < nch; k++) {
-                    const int32_t c0 = k * LONG_CH, c1 = c0 + LONG_CH < deg ? c0 + LONG_CH : deg;
+                    const int32_t c0 = k * long_ch, c1 = c0 + long_ch < deg ? c0 + long_ch : deg;
                     const int32_t e[4] = {(int32_t)long_row.size(), lb + c0, lb + c1, k};
                     chunks.insert(chunks.end(), e, e + 4);
                 }
@@ -1495,8 +1509,10 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
                 int32_t *dh = nullptr;
                 ok = hipMalloc((void **)&dh, sizeof(int32_t) * hubs.size()) == hipSuccess &&
                      hipMemcpy(dh, hubs.data(), sizeof(int32_t) * hubs.size(), hipMemcpyHostToDevice) == hipSuccess;
-                if (ok) ok = lgcn_graph_create(c.graph->indptr, c.graph->indices, c.graph->vals, x->N, c.graph->nnz, c.d, dh,
-                                               (int64_t)hubs.size(), nullptr, &x->hub_graph) == 0;
+                int32_t hub_chunk = TRIPLET_HUB_CHUNK;
+                if (const char *e2 = getenv("LGCN_TRIPLET_HUB_CHUNK")) hub_chunk = atoi(e2) > 0 ? atoi(e2) : hub_chunk;
+                if (ok) ok = graph_create_impl(c.graph->indptr, c.graph->indices, c.graph->vals, x->N, c.graph->nnz, c.d, dh,
+                                               (int64_t)hubs.size(), nullptr, hub_chunk, &x->hub_graph) == 0;
                 if (dh) (void)hipFree(dh);
                 x->hub_nnz = thr;
             }
