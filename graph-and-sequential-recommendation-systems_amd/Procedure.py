@@ -27,11 +27,20 @@ CORES = multiprocessing.cpu_count() // 2
 def sample_epoch_to_device(dataset, device):
     """Sample (utils.UniformSample_original), upload, shuffle (utils.shuffle) -- the
     semantics of main.py:216-220.  Returns int32 device tensors users, pos, neg [T]."""
+    S32 = None
     if (torch.device(device).type == 'cuda' and int(world.config.get('gpu_sampler', 1)) and utils.sample_ext
             and utils.sampler_mode(dataset) == 'cpp'):
         # the native sampler's stream and rows, produced on the device (sampling.cpp:27-56, bit-exact)
-        S32 = utils.sampling.sample_negative_device(dataset.n_users, dataset.m_items, dataset.trainDataSize,
-                                                    utils._pos_csr(dataset), device)
+        try:
+            S32 = utils.sampling.sample_negative_device(dataset.n_users, dataset.m_items, dataset.trainDataSize,
+                                                        utils._pos_csr(dataset), device)
+        except _lib.LgcnError as e:
+            # rc 5: a dense dataset rejected more negatives than the device stream's margin (T/50 + 65536 draws) holds.
+            # The host generator has not been advanced yet, so the bit-exact host sampler takes this epoch over.
+            if "(rc=5)" not in str(e):
+                raise
+            world.cprint("[sampler] GPU sampler margin exceeded (dense dataset): host sampler for this epoch")
+    if S32 is not None:
         T = int(S32.shape[0])
         perm = utils.shuffle_indices(T)
     else:

@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -24,11 +24,12 @@ class TrainConfig(C.Structure):
         ("graph", _vp),
         ("n_users", C.c_int32), ("d", C.c_int32), ("K", C.c_int32), ("act_dtype", C.c_int32),
         ("E0", _vp), ("adam_m", _vp), ("adam_v", _vp),
-        ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("ebuf", _vp), ("contrib", _vp),
+        ("act", _vp), ("G64", _vp), ("bitmap", _vp), ("terms", _vp), ("contrib", _vp),
         ("err", _vp), ("max_batch", C.c_int32),
         ("decay", C.c_float),
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
         ("xcd_remap", C.c_int32), ("dense_last", C.c_int32),
+        ("hub_nnz", C.c_int32), ("hub_chunk", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "lgcn_ctx_create": (C.c_int, [C.POINTER(TrainConfig), C.POINTER(_vp)]),
     "lgcn_ctx_destroy": (None, [_vp]),
     "lgcn_ctx_get_step": (C.c_int64, [_vp]),
+    "lgcn_ctx_hub_rows": (C.c_int64, [_vp]),
     "lgcn_ctx_set_step": (None, [_vp, C.c_int64]),
     "lgcn_ctx_set_lr": (None, [_vp, C.c_double]),
     "lgcn_ctx_set_dp_local": (C.c_int, [_vp, C.c_int]),

@@ -775,7 +775,6 @@ struct BprArgs {
     int32_t shard;        // row stride of the contrib block (>= B_local)
     float inv_B;          // 1 / global batch
     float lam;            // decay / global batch
-    float *ebuf;          // (unused since run 56: the slot rows stay in registers / LDS; the configuration field remains)
     long long *G64;       // if non-null: atomics
     uint32_t *bitmap;
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
@@ -1460,6 +1459,7 @@ struct lgcn_ctx {
     bool in_loop;                 // inside lgcn_train_epoch / lgcn_train_epoch_dp: the Adam epilogue keeps e0b current
     lgcn_graph *hub_graph;        // plan over the rows with more than hub_nnz non-zeros (or NULL): their last-layer rows are
     int32_t hub_nnz;              //   computed by k_spmm into g32 before k_triplet instead of by the one workgroup of a triplet
+    int64_t hub_rows;             // rows in that plan
     bool dp_local;                // data parallel (rows): part 1 also adds this rank's own rows into G64, part 2 scatters the others'
     int dp_rank;                  // rank of the last part 1
 };
@@ -1474,7 +1474,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (!cfg || !out) { lgcn_set_error("lgcn_ctx_create: null argument"); return 3; }
     const lgcn_train_config &c = *cfg;
     if (!c.graph || !c.E0 || !c.adam_m || !c.adam_v || !c.G64 ||
-        !c.bitmap || !c.terms || !c.ebuf || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
+        !c.bitmap || !c.terms || !c.err) { lgcn_set_error("lgcn_ctx_create: null buffer"); return 3; }
     if (c.K < 1 || c.K > LGCN_MAX_LAYERS) { lgcn_set_error("lgcn_ctx_create: K out of range"); return 3; }
     if ((c.K > 1 || c.dense_last) && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
@@ -1491,7 +1491,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
     x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
-    x->hub_graph = nullptr; x->hub_nnz = 0;
+    x->hub_graph = nullptr; x->hub_nnz = 0; x->hub_rows = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
@@ -1499,8 +1499,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
         // Rows too long for one workgroup (a 800 000-neighbour item of the 10M x 1M graph kept ONE k_triplet workgroup busy
         // for 37 ms, several times per batch): a plan over just those rows; k_spmm computes their last-layer rows for
         // the whole chip to share, once per step, before k_triplet.
-        int32_t thr = TRIPLET_HUB_NNZ;
-        if (const char *e = getenv("LGCN_TRIPLET_HUB_NNZ")) thr = atoi(e);
+        const int32_t thr = c.hub_nnz == 0 ? TRIPLET_HUB_NNZ : c.hub_nnz;
         if (thr > 0) {
             std::vector<int32_t> ip((size_t)x->N + 1), hubs;
             ok = hipMemcpy(ip.data(), c.graph->indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost) == hipSuccess;
@@ -1509,12 +1508,11 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
                 int32_t *dh = nullptr;
                 ok = hipMalloc((void **)&dh, sizeof(int32_t) * hubs.size()) == hipSuccess &&
                      hipMemcpy(dh, hubs.data(), sizeof(int32_t) * hubs.size(), hipMemcpyHostToDevice) == hipSuccess;
-                int32_t hub_chunk = TRIPLET_HUB_CHUNK;
-                if (const char *e2 = getenv("LGCN_TRIPLET_HUB_CHUNK")) hub_chunk = atoi(e2) > 0 ? atoi(e2) : hub_chunk;
+                const int32_t hub_chunk = c.hub_chunk > 0 ? c.hub_chunk : TRIPLET_HUB_CHUNK;
                 if (ok) ok = graph_create_impl(c.graph->indptr, c.graph->indices, c.graph->vals, x->N, c.graph->nnz, c.d, dh,
                                                (int64_t)hubs.size(), nullptr, hub_chunk, &x->hub_graph) == 0;
                 if (dh) (void)hipFree(dh);
-                x->hub_nnz = thr;
+                x->hub_nnz = thr; x->hub_rows = (int64_t)hubs.size();
             }
         }
     }
@@ -1542,6 +1540,7 @@ extern "C" int lgcn_ctx_set_dp_local(lgcn_ctx *ctx, int on) {
     return 0;
 }
 extern "C" int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx) { return ctx ? ctx->step : -1; }
+extern "C" int64_t lgcn_ctx_hub_rows(const lgcn_ctx *ctx) { return (ctx && ctx->hub_graph) ? ctx->hub_rows : 0; }
 extern "C" void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t s) { if (ctx) ctx->step = s; }
 extern "C" void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr) { if (ctx) ctx->c.lr = lr; }
 
@@ -1588,7 +1587,6 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err; a.exchange = exchange ? 1 : 0;
     a.terms_off = exchange ? 0 : b_off; a.terms_stride = B_global;
-    a.ebuf = c.ebuf;
     if (x->hub_graph && !c.dense_last && B_local > 0) {
         // last layer of the hub rows, X_K[hub] = (A_hat X_{K-1})[hub] in fp32, into the library's [N,d] table (free until k_g32)
         { int rc0 = graph_acquire(x->hub_graph, st); if (rc0) return rc0; }

@@ -190,8 +190,12 @@ class LightGCN(nn.Module):
             self._dev['graph_rs'].close()
         if self._dev is not None and self._dev.get('graph') is not None:
             self._dev['graph'].close()
+        for key in ('i2i', 'i2i_t'):
+            if self._dev is not None and self._dev.get(key) is not None:
+                self._dev[key].close()
         self._dev = None
         self._cache = None
+        self._rating_cache = None
 
     def __del__(self):
         try:
@@ -224,15 +228,18 @@ class LightGCN(nn.Module):
             g = st['graph']
             st['graph_rs'] = _lib.Graph(g.indptr, g.indices, g.vals, d_max=self.latent_dim,
                                         row_order=np.ascontiguousarray(row_subset, np.int32))
-            if st['ctx'] is not None:
-                self._make_ctx(st['max_batch'], st.get('dp_world', 1))
         if need_ctx:
             max_batch = int(max_batch or self.config.get('bpr_batch_size', 2048))
-            if st['ctx'] is None or st['max_batch'] < max_batch or st.get('dp_world', 1) != dp_world:
-                self._make_ctx(max_batch, dp_world)
+            # a context is bound to ONE plan: the owned rows (row-sharded epochs, which exchange the other rows) or all
+            # rows (every other caller: fused_step / fused_epoch / stageOne / batch-sharded data parallel).  A context
+            # made for one must not serve the other -- it would propagate over the owned rows only, with no exchange.
+            rows = 'owned' if row_subset is not None else 'all'
+            if (st['ctx'] is None or st['max_batch'] < max_batch or st.get('dp_world', 1) != dp_world
+                    or st.get('ctx_rows', 'all') != rows):
+                self._make_ctx(max_batch, dp_world, rows)
         return st
 
-    def _make_ctx(self, max_batch, dp_world):
+    def _make_ctx(self, max_batch, dp_world, rows=None):
         st, dev = self._dev, self._table.device
         lib = _lib.load()
         old_step = 0
@@ -251,29 +258,31 @@ class LightGCN(nn.Module):
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
         st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
         st['terms'] = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
-        st['ebuf'] = torch.zeros(3 * max_batch * d, dtype=torch.float32, device=dev)
         shard = (max_batch + dp_world - 1) // dp_world
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
         cfg = _lib.TrainConfig()
-        cfg.graph = (st.get('graph_rs') or st['graph']).handle
+        rows = rows or st.get('ctx_rows', 'all')
+        cfg.graph = (st['graph_rs'] if rows == 'owned' else st['graph']).handle
         cfg.n_users, cfg.d, cfg.K = self.n_users, d, K
         cfg.act_dtype = act_dtype
         cfg.E0, cfg.adam_m, cfg.adam_v = self._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
         cfg.act, cfg.G64 = st['act'].data_ptr(), st['G64'].data_ptr()
         cfg.bitmap, cfg.terms, cfg.contrib = st['bitmap'].data_ptr(), st['terms'].data_ptr(), st['contrib'].data_ptr()
-        cfg.ebuf = st['ebuf'].data_ptr()
         cfg.err, cfg.max_batch = st['err'].data_ptr(), max_batch
         cfg.decay = float(self.config.get('decay', 1e-4))
         cfg.lr = float(self.config.get('lr', 1e-3))
         cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.999, 1e-8
         cfg.xcd_remap = int(self.config.get('xcd_remap', 1))
         cfg.dense_last = int(dense_last)
+        cfg.hub_nnz = int(self.config.get('hub_nnz', 0))          # 0: library default; < 0: off
+        cfg.hub_chunk = int(self.config.get('hub_chunk', 0))
         st['dense_last'] = dense_last
         h = C.c_void_p()
         _lib.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "lgcn_ctx_create")
         lib.lgcn_ctx_set_step(h, old_step)
         st['ctx'], st['max_batch'], st['dp_world'], st['table_ptr'] = h, max_batch, dp_world, self._table.data_ptr()
+        st['ctx_rows'] = rows
 
     def _dense_last(self, batch):
         """Last forward layer: on the 3B batch rows only (default) or densely?  The batch rows hold an

@@ -130,11 +130,20 @@ class DataParallelBPR:
         if self._comm is None:
             lib = _lib.load()
             buf = (C.c_char * 128)()
+            err0 = None
             if self.rank == 0:
-                _lib.check(lib.lgcn_dp_unique_id(buf), "lgcn_dp_unique_id")
-            box = [bytes(buf)]
+                # a failure here must not keep rank 0 out of the broadcast the other ranks are already waiting in:
+                # it sends an empty id instead, and every rank treats that as "no communicator" (same collective
+                # sequence on every rank: broadcast, then the all-reduce of _own_communicator_ok)
+                try:
+                    _lib.check(lib.lgcn_dp_unique_id(buf), "lgcn_dp_unique_id")
+                except Exception as e:      # noqa: BLE001
+                    err0 = e
+            box = [b"" if err0 is not None else bytes(buf)]
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                        group=self.group)
+            if len(box[0]) != 128:
+                raise err0 if err0 is not None else _lib.LgcnError("rank 0 could not create the RCCL unique id")
             h = C.c_void_p()
             _lib.check(lib.lgcn_dp_init(box[0], self.world, self.rank, C.byref(h)), "lgcn_dp_init")
             self._comm = h
@@ -147,10 +156,18 @@ class DataParallelBPR:
         step instead of per epoch.  (Row-sharded propagation has no such loop and raises.)"""
         if self._comm_ok is None:
             err = None
-            try:
-                self._communicator()
-            except Exception as e:      # noqa: BLE001 -- reported below, decided collectively
-                err = e
+            dev = self.model._table.device
+            # stage 1: can every rank resolve RCCL at all?  ncclCommInitRank is itself a collective: a rank that cannot
+            # even load the library must keep the others from entering it.
+            have = torch.tensor([1 if _lib.load().lgcn_dp_available() else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN, group=self.group)
+            if int(have.item()) == 0:
+                err = _lib.LgcnError("librccl could not be resolved on every rank")
+            else:
+                try:
+                    self._communicator()
+                except Exception as e:      # noqa: BLE001 -- reported below, decided collectively
+                    err = e
             flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.model._table.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
             self._comm_ok = int(flag.item()) == 0
@@ -186,6 +203,9 @@ class DataParallelBPR:
         dev = m._table.device
         T = int(users.numel())
         if dev.type != 'cuda' or os.environ.get("LGCN_DP_PYTHON_LOOP") == "1" or not self._own_communicator_ok():
+            if self.shard == 'rows':        # (no per-step form exists: _step would come straight back here)
+                raise RuntimeError("row-sharded propagation (shard='rows') runs only through the library's RCCL communicator "
+                                   "on CUDA tensors; it has no torch.distributed per-step loop (LGCN_DP_PYTHON_LOOP / CPU)")
             out = [self._step(users[t:t + global_batch], pos[t:t + global_batch], neg[t:t + global_batch])
                    for t in range(0, T, global_batch)]
             return torch.stack(out)

@@ -9,6 +9,11 @@ replacement per user, every user >= 1 item (so the native sampler is defined).
 Everything is vectorised (torch ops; runs on the GPU when one is given, else on the CPU)
 and hands back CSR arrays directly -- no text file, no per-user Python loop -- so the
 200 M-edge graph is built in seconds on an MI355X.
+
+Reproducibility: the degree sequence and the popularity ranks come from numpy PCG64(seed) and are
+the same everywhere; the item draws use torch's generator OF THE GIVEN DEVICE, so a seed names one
+graph per device type (CPU vs GPU), not one graph overall.  Every measurement and parity test in
+this repository builds and checks its graph in the same process, on the same device.
 """
 import numpy as np
 import torch

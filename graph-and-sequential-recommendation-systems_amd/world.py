@@ -102,6 +102,7 @@ def configure(argv=None):
     config['eval_fused'] = args.eval_fused
     config['gpu_sampler'] = args.gpu_sampler
     config['dense_last'] = args.dense_last
+    config['hub_nnz'] = args.hub_nnz
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

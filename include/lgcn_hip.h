@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 7
+#define LGCN_ABI_VERSION 8
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -162,7 +162,6 @@ typedef struct {
     int64_t *G64;               /* [N,d] fixed-point (2^50) accumulator of the sparse-row gradient */
     uint32_t *bitmap;           /* [2*ceil(N/32)] rows of G64 that are non-zero (two, used alternately) */
     float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
-    float *ebuf;                /* [3*max_batch*d] workspace, non-NULL (no longer written: the batch slot rows stay on chip) */
     float *contrib;             /* [3*max_batch*d + 2*max_batch] (data-parallel exchange buffer) or NULL */
     int32_t *err;               /* [1] device error flag */
     int32_t max_batch;
@@ -173,6 +172,12 @@ typedef struct {
     int32_t dense_last;         /* 1: propagate the LAST layer densely too and read the batch rows from it (needs K
                                    activation buffers); 0: compute it only on the 3B batch rows (K-1 buffers).  Pays
                                    when the batch rows together hold more non-zeros than the graph (hub-heavy data) */
+    /* hub plan of the batch-row kernel (dense_last = 0): rows with more than hub_nnz non-zeros get their last-layer row
+     * from a whole-chip SpMM over just those rows, once per step, instead of from the one workgroup of each triplet
+     * that names them.  0 = library default (131072), < 0 = no hub plan.  hub_chunk: non-zeros per chunk of those
+     * rows (0 = default 2048).  Neither changes the algorithm, only who sums a hub row (fp32 summation order). */
+    int32_t hub_nnz;
+    int32_t hub_chunk;
 } lgcn_train_config;
 
 /* Besides the caller's workspace the context owns device allocations made here with hipMalloc and released by
@@ -182,6 +187,8 @@ int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out);
 void lgcn_ctx_destroy(lgcn_ctx *ctx);
 /* optimizer step counter (torch Adam state['step']) for checkpoint/resume */
 int64_t lgcn_ctx_get_step(const lgcn_ctx *ctx);
+/* number of rows in the context's hub plan (0: none was built) */
+int64_t lgcn_ctx_hub_rows(const lgcn_ctx *ctx);
 void lgcn_ctx_set_step(lgcn_ctx *ctx, int64_t step);
 void lgcn_ctx_set_lr(lgcn_ctx *ctx, double lr);
 /* Data parallel, rows mode: 1 = part 1 of a step also adds this rank's OWN gradient rows into its G64 (besides writing

@@ -59,6 +59,29 @@ def read_interactions(path):
     return np.asarray(users, np.int64), np.asarray(items, np.int64)
 
 
+EPS32 = 2.0 ** -24        # unit roundoff of fp32
+
+
+def spmm_sum_bound(indptr, vals, indices, X, extra_terms=2):
+    """Rigorous first-order bound on |a - b| for two fp32 evaluations a, b of the row sums  y_i = sum_j v_ij x_j  that
+    differ only in summation order / FMA contraction: each evaluation errs by at most (n_i + 1) * u * sum_j |v_ij x_j|
+    (n_i terms: n_i - 1 additions + one rounding per product, u = 2^-24), whatever its order.  -> [rows, d] float64 =
+    (2 n_i + extra_terms) * u * S_i, with S_i = sum_j |v_ij| |x_j| evaluated in float64.  Used instead of literal
+    absolute tolerances wherever a row has hundreds to a million terms."""
+    import scipy.sparse as sp
+    indptr = np.asarray(indptr, np.int64)
+    n = np.diff(indptr)
+    A = sp.csr_matrix((np.abs(np.asarray(vals, np.float64)), np.asarray(indices), indptr), shape=(len(n), X.shape[0]))
+    S = A @ np.abs(np.asarray(X, np.float64))
+    return (2.0 * n + extra_terms)[:, None] * EPS32 * S + 1e-37
+
+
+def assert_rows_close(got, ref, bound, what=""):
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    bad = err > bound
+    assert not bad.any(), (what, int(bad.sum()), float(err[bad].max()), float(bound[bad].min()), np.argwhere(bad)[:4].tolist())
+
+
 class GoldenSet:
     """A golden fixture directory: train/test lists + golden.npz/json."""
 

@@ -5,22 +5,29 @@ the last row, 4 096 random ones -- the oracle runs on the sub-problem those rows
 torch's own sparse kernels on the whole matrix (an independent implementation on the same device)
 and through size-independent properties."""
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
+from conftest import EPS32, assert_rows_close, spmm_sum_bound
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _oracle_rows(oracle, A, X, rows):
+def _oracle_rows(oracle, A, X, rows, with_bound=False):
     """oracle.spmm restricted to `rows`: the sub-matrix of those rows with its columns relabelled
-    compactly, times the gathered slice of X (same arithmetic, same order within a row)."""
+    compactly, times the gathered slice of X (same arithmetic, same order within a row).  with_bound: also the
+    per-element bound (2 n + 2) * 2^-24 * sum |v x| on the difference of two fp32 summation orders of such a row."""
     sub = A[rows]
     cols, inv = np.unique(sub.indices, return_inverse=True)
-    xs = X[torch.from_numpy(cols).to(X.device).long()].cpu().numpy()
-    return oracle.spmm(sub.indptr.astype(np.int32), inv.astype(np.int32), sub.data, xs)
+    xs = X[torch.from_numpy(cols).to(X.device).long()].float().cpu().numpy()
+    ref = oracle.spmm(sub.indptr.astype(np.int32), inv.astype(np.int32), sub.data, xs)
+    if not with_bound:
+        return ref
+    return ref, spmm_sum_bound(sub.indptr, sub.data, inv, xs)
 
 
 @pytest.mark.skipif(os.environ.get("LGCN_SKIP_LARGE") == "1", reason="LGCN_SKIP_LARGE=1")
@@ -49,10 +56,10 @@ def test_nine_million_rows_dim256(pkg, oracle):
     Y = g.spmm(X)
     sample = np.unique(np.concatenate([np.flatnonzero(np.diff(A.indptr) > 64)[:64], [0, 1, 2, N - 1],
                                        rng.integers(0, N, 4096)]))
-    ref_rows = _oracle_rows(oracle, A, X, sample)
+    ref_rows, bound = _oracle_rows(oracle, A, X, sample, with_bound=True)
     got_rows = Y[torch.from_numpy(sample).to(DEV)].cpu().numpy()
-    # (the sample holds the 3000- and 700-term rows: partial sums reach ~1, so 5e-6 absolute)
-    np.testing.assert_allclose(got_rows, ref_rows, rtol=2e-5, atol=5e-6)
+    # the sample holds the 3000- and 700-term rows; the bound is computed per row: (2 n + 2) * 2^-24 * sum |v x|
+    assert_rows_close(got_rows, ref_rows, bound, "9M-row graph, sampled rows")
     At = torch.sparse_csr_tensor(ip.long(), ix.long(), vv, size=(N, N), device=DEV)
     Yref = torch.sparse.mm(At, X)
     err = float((Y - Yref).abs().max()); scale = float(Yref.abs().max())
@@ -72,11 +79,11 @@ def test_nine_million_rows_dim256(pkg, oracle):
     act = torch.zeros(1, N, d, device=DEV)
     G64 = torch.zeros(N, d, dtype=torch.int64, device=DEV)
     bitmap = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=DEV)
-    terms = torch.zeros(2 * B, device=DEV); ebuf = torch.zeros(3 * B * d, device=DEV); errf = torch.zeros(1, dtype=torch.int32, device=DEV)
+    terms = torch.zeros(2 * B, device=DEV); errf = torch.zeros(1, dtype=torch.int32, device=DEV)
     cfg = L.TrainConfig()
     cfg.graph = g.handle; cfg.n_users, cfg.d, cfg.K, cfg.act_dtype = n_users, d, K, 0
     cfg.E0, cfg.adam_m, cfg.adam_v = E0.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
-    cfg.act, cfg.G64, cfg.bitmap, cfg.terms, cfg.ebuf = act.data_ptr(), G64.data_ptr(), bitmap.data_ptr(), terms.data_ptr(), ebuf.data_ptr()
+    cfg.act, cfg.G64, cfg.bitmap, cfg.terms = act.data_ptr(), G64.data_ptr(), bitmap.data_ptr(), terms.data_ptr()
     cfg.contrib, cfg.err, cfg.max_batch, cfg.decay = None, errf.data_ptr(), B, 1e-4
     cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = 1e-3, 0.9, 0.999, 1e-8, 1
     h = C.c_void_p()
@@ -100,3 +107,114 @@ def test_nine_million_rows_dim256(pkg, oracle):
     assert int(G64.abs().sum()) == 0
     L.load().lgcn_ctx_destroy(h)
     g.close()
+
+
+@pytest.mark.skipif(os.environ.get("LGCN_SKIP_LARGE") == "1", reason="LGCN_SKIP_LARGE=1")
+def test_c5_full_shape(pkg, oracle):
+    """BASELINE configs[4] ITSELF: bench.py's generator (10 M users x 1 M items, E = 200 M, seed 2020), K = 3, d = 256,
+    B = 2048, natural row order -- the workload `bench.py --workload synthetic-10m` times -- with the hub plan of the
+    batch-row kernel at its PRODUCTION threshold (131 072 non-zeros, chunks of 2 048; rows of up to ~800 000 non-zeros).
+      * the context builds a hub plan (and none with hub_nnz < 0);
+      * every propagation layer X_k = A X_{k-1}, k = 1..3, against the oracle on a row sample that holds EVERY row
+        longer than the threshold, the first and the last row, and 4 096 random rows (layer by layer: the oracle's
+        input of layer k is the GPU's X_{k-1}, so each launch is checked on its own inputs), within the computed bound
+        (2 n + 2) * 2^-24 * sum |v x| per element; lgcn_propagate_mean against (X_0 + .. + X_3) / 4 of those layers;
+      * one fused step, fp32 and bf16 activation storage: loss against the loss recomputed from the propagated rows
+        of the batch, Adam's first step bounded by lr, G64 left clean, and hub plan on / off equal to 2e-7 (loss) and
+        1e-6 (parameters: the two differ in the summation order of the hub rows only)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    L, lib = pkg._lib, pkg._lib.load()
+    name = "synthetic-10m"
+    n_users, m_items, E, K, d, B = bench.WORKLOADS[name][:6]
+    assert (n_users, m_items, E, K, d, B) == (10_000_000, 1_000_000, 200_000_000, 3, 256, 2048)
+    w = pkg.world
+    w.configure(["--dataset", name, "--tensorboard", "0", "--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B),
+                 "--act_dtype", "fp32", "--row_order", "natural", "--dense_last", "auto"])
+    ds = bench.synthetic_dataset(pkg, name, w.config, DEV)
+    assert ds.trainDataSize == E
+    adj = ds.getSparseGraphCSR()
+    N = n_users + m_items
+    deg = np.diff(adj.indptr)
+    hubs = np.flatnonzero(deg > 131072)
+    assert adj.shape == (N, N) and adj.nnz == 2 * E and len(hubs) >= 1 and deg.max() > 500_000
+    pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+    m = pkg.model.LightGCN(w.config, ds).to(DEV)
+    assert not m._dense_last(B)                       # the batch-row kernel (and with it the hub plan) is what C5 runs
+    rng = np.random.Generator(np.random.PCG64(5))
+    sample = np.unique(np.concatenate([hubs, [0, n_users - 1, n_users, N - 1], rng.integers(0, N, 4096)]))
+    sample_t = torch.from_numpy(sample).to(DEV)
+
+    # ---- propagation, layer by layer, then the mean
+    g = m._state()['graph']
+    X = [m._table.detach()]
+    for k in range(1, K + 1):
+        X.append(g.spmm(X[-1]))
+        ref, bound = _oracle_rows(oracle, adj, X[k - 1], sample, with_bound=True)
+        assert_rows_close(X[k][sample_t].cpu().numpy(), ref, bound, f"C5 layer {k}")
+        del ref, bound
+    with torch.no_grad():
+        out = m._propagate_dense()
+    mean_rows = (X[0][sample_t] + X[1][sample_t] + X[2][sample_t] + X[3][sample_t]) / 4.0
+    assert float((out[sample_t] - mean_rows).abs().max()) <= 4 * EPS32 * float(mean_rows.abs().max()) + 1e-9
+    chk = rng.integers(0, N, 200_000)
+    chk_t = torch.from_numpy(chk).to(DEV)
+    mean_chk = (X[0][chk_t] + X[1][chk_t] + X[2][chk_t] + X[3][chk_t]) / 4.0
+    assert float((out[chk_t] - mean_chk).abs().max()) <= 4 * EPS32 * float(mean_chk.abs().max()) + 1e-9
+    del X, mean_rows, mean_chk, out
+
+    # ---- one fused step per mode on the same batch; the top hub is the positive of several triplets
+    users = rng.integers(0, n_users, B).astype(np.int32)
+    S = pkg.sampling.sample_negative_ByUser(users, m_items, ds.pos_csr(), 1)
+    u, p, n = (torch.from_numpy(np.ascontiguousarray(S[:, c])).to(DEV) for c in range(3))
+    top_item = int(np.argmax(deg[n_users:]))
+    p[:4] = top_item; n[5] = top_item
+    E0 = m._table.detach().clone()
+    lr = float(w.config['lr'])
+
+    def loss_from(table):
+        eu, ep, en = table[u.long()], table[n_users + p.long()], table[n_users + n.long()]
+        x = (eu * ep).sum(1) - (eu * en).sum(1)
+        return float(-torch.nn.functional.logsigmoid(x).mean()), float(0.5 * (eu.pow(2).sum() + ep.pow(2).sum() + en.pow(2).sum()) / B)
+
+    def one_step(act, hub_nnz):
+        with torch.no_grad():
+            m._table.copy_(E0)
+        m.config['act_dtype'] = act; m.config['hub_nnz'] = hub_nnz
+        st = m._state()
+        for k_ in ('adam_m', 'adam_v'):
+            if k_ in st:
+                st[k_].zero_()
+        m._make_ctx(B, 1)
+        st = m._dev
+        lib.lgcn_ctx_set_step(st['ctx'], 0)
+        rows = int(lib.lgcn_ctx_hub_rows(st['ctx']))
+        loss = m.fused_step(u, p, n).cpu().numpy().copy()
+        torch.cuda.synchronize()
+        m.check_device_errors()
+        assert not bool(st['G64'].any())                             # the step left its accumulator clean
+        return rows, loss, m._table.detach()[chk_t].clone(), m._table.detach()[sample_t].clone()
+
+    for act in ("fp32", "bf16"):
+        m.config['act_dtype'] = act
+        with torch.no_grad():
+            m._table.copy_(E0)
+            m.invalidate_cache()
+            table = m._propagate_dense()                              # the rows bpr_loss gathers, in this storage mode
+        bpr_ref, reg_ref = loss_from(table)
+        del table
+        rows_on, loss_on, chk_on, smp_on = one_step(act, 0)              # library default = production threshold 131 072
+        assert rows_on == len(hubs)
+        assert abs(float(loss_on[1]) - bpr_ref) < 2e-6 and abs(float(loss_on[2]) - reg_ref) < 2e-6 * max(1.0, reg_ref), (act, loss_on, bpr_ref, reg_ref)
+        assert abs(float(loss_on[0]) - (bpr_ref + float(w.config['decay']) * reg_ref)) < 2e-6
+        delta = (m._table.detach() - E0).abs()
+        assert bool(torch.isfinite(m._table).all()) and float(delta.max()) <= 1.001 * lr     # Adam's first step moves <= lr
+        assert int((delta.amax(1) > 0).sum()) > 3 * B                     # and reaches far more rows than the batch names
+        assert float(delta[n_users + top_item].max()) > 0
+        del delta
+        rows_off, loss_off, chk_off, smp_off = one_step(act, -1)
+        assert rows_off == 0
+        assert np.abs(loss_on - loss_off).max() <= 2e-7, (act, loss_on, loss_off)
+        assert float((chk_on - chk_off).abs().max()) <= 1e-6 and float((smp_on - smp_off).abs().max()) <= 1e-6
+    m._drop_device_state()

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, assert_rows_close, spmm_sum_bound
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -505,13 +505,12 @@ def test_fused_steps_other_dims_vs_oracle(pkg, oracle, tmp_path, d, K, act):
 
 @pytest.mark.parametrize("hub", [0, 200])
 @pytest.mark.parametrize("d,K,act", [(64, 3, "fp32"), (32, 1, "fp32"), (256, 2, "fp32"), (128, 3, "bf16")])
-def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, monkeypatch, d, K, act, hub):
+def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act, hub):
     """k_triplet cuts a slot row into units of 128 non-zeros dealt to the workgroup's four waves: batches whose user /
     positive / negative rows sit exactly on and around every unit and wave-wrap boundary (1 ... 1300 non-zeros,
     item hubs of 350 / 700 / 1400), duplicates of the same hub in one batch, vs the oracle's stageOne."""
     # hub = 200: rows with more than 200 non-zeros take the hub plan (k_spmm computes their last-layer rows for k_triplet to
-    # read) -- the production threshold is 32 768 and only the 10M x 1M graph crosses it
-    monkeypatch.setenv("LGCN_TRIPLET_HUB_NNZ", str(hub))
+    # read) -- the production threshold is 131 072 and only the 10M x 1M graph crosses it (tests/test_gpu_large.py runs that)
     lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640, 1025, 1300]
     n_users = m_items = 1400
     path = os.path.join(str(tmp_path), f"units{d}")
@@ -529,7 +528,7 @@ def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, monkeypatch, d, K
             ft.write(f"{u} {int(rng.integers(0, m_items))}\n")
     w = pkg.world
     w.configure(["--dataset", "units", "--tensorboard", "0", "--layer", str(K), "--recdim", str(d),
-                 "--bpr_batch", "128", "--act_dtype", act, "--dense_last", "0"])
+                 "--bpr_batch", "128", "--act_dtype", act, "--dense_last", "0", "--hub_nnz", str(hub if hub else -1)])
     ds = pkg.dataloader.Loader(w.config, path=path)
     pkg.utils.set_seed(3)
     m = pkg.model.LightGCN(w.config, ds).to(DEV)
@@ -666,14 +665,16 @@ def test_spmm_row_length_boundaries(pkg, oracle, d):
     vals = rng.uniform(0.01, 0.4, len(indices)).astype(np.float32)
     X = rng.normal(0, 0.1, (n, d)).astype(np.float32)
     ref = oracle.spmm(indptr, indices, vals, X)
+    bound = spmm_sum_bound(indptr, vals, indices, X)
     first = None
     cut = np.array([0, 10, 10, 300, 700, 701, 1200, 1599, 1600], np.int64)
     for order, xs in ((None, None), (rng.permutation(n).astype(np.int32), None), (rng.permutation(n).astype(np.int32), cut)):
         g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order, xcd_start=xs)
         got = g.spmm(_dev(X)).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=4e-6)          # rows of up to 1537 terms of |v x| <= 0.1: partial sums reach ~3
+        # bound per row = (2 n + 2) * 2^-24 * sum |v x|: two fp32 summation orders of the same n terms (conftest.spmm_sum_bound)
+        assert_rows_close(got, ref, bound, "first launch")
         again = g.spmm(_dev(2.0 * X)).cpu().numpy()    # other data through the same scratch: tickets were reset, no stale partial
-        np.testing.assert_allclose(again, 2.0 * ref, rtol=2e-5, atol=8e-6)      # doubled data
+        assert_rows_close(again, 2.0 * ref, 2.0 * bound, "doubled data")
         third = g.spmm(_dev(X)).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), third.view(np.uint32))
         if first is None:
@@ -894,7 +895,7 @@ def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, 
         cfg.n_users, cfg.d, cfg.K, cfg.act_dtype = ds.n_users, g.d, g.K, 0
         cfg.E0, cfg.adam_m, cfg.adam_v = m._table.data_ptr(), st['adam_m'].data_ptr(), st['adam_v'].data_ptr()
         cfg.act, cfg.G64, cfg.bitmap = st['act'].data_ptr(), st['G64'].data_ptr(), st['bitmap'].data_ptr()
-        cfg.terms, cfg.ebuf, cfg.contrib = st['terms'].data_ptr(), st['ebuf'].data_ptr(), st['contrib'].data_ptr()
+        cfg.terms, cfg.contrib = st['terms'].data_ptr(), st['contrib'].data_ptr()
         cfg.err, cfg.max_batch, cfg.decay = st['err'].data_ptr(), B, float(g.meta["decay"])
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.xcd_remap = float(g.meta["lr"]), 0.9, 0.999, 1e-8, 1
         cfg.dense_last = int(st['dense_last'])               # same last-layer mode as the reference run
@@ -979,6 +980,38 @@ def test_gpu_sampler_bit_exact(pkg, oracle, tiny, tmp_path):
     for prefix in ("978d20809083cea5", "dcfb3021bcc6755a"):
         Sg = S.sample_negative_device(gds.n_users, gds.m_items, gds.trainDataSize, gds.pos_csr(), DEV).cpu().numpy()
         assert Sg.shape == (806166, 3) and hashlib.sha256(Sg.tobytes()).hexdigest().startswith(prefix)
+
+
+def test_gpu_sampler_margin_falls_back_to_host(pkg, tmp_path):
+    """A dense dataset (every user holds 90 % of the items: ~9 rejected negatives per triplet) exceeds the device sampler's
+    stream margin (T/50 + 65536 draws): lgcn_sample_negative_device returns rc 5 WITHOUT advancing the host generator
+    and Procedure.sample_epoch_to_device hands that epoch to the bit-exact host sampler -- the epoch's triplets are
+    the ones --gpu_sampler 0 produces, and training goes on."""
+    n_users, m_items, keep = 2000, 200, 180
+    rng = np.random.Generator(np.random.PCG64(4))
+    path = os.path.join(str(tmp_path), "dense")
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "train.txt"), "w") as f, open(os.path.join(path, "test.txt"), "w") as ft:
+        for u in range(n_users):
+            items = np.sort(rng.choice(m_items, size=keep, replace=False))
+            f.write(f"{u} " + " ".join(map(str, items.tolist())) + "\n")
+            ft.write(f"{u} {int(rng.integers(0, m_items))}\n")
+    w = pkg.world
+    out = []
+    for gpu in (1, 0):
+        w.configure(["--dataset", "dense", "--tensorboard", "0", "--gpu_sampler", str(gpu), "--prefetch_epoch", "0"])
+        ds = pkg.dataloader.Loader(w.config, path=path)
+        pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+        if gpu:
+            with pytest.raises(pkg._lib.LgcnError, match="rc=5"):
+                pkg.sampling.sample_negative_device(ds.n_users, ds.m_items, ds.trainDataSize, ds.pos_csr(), DEV)
+        epochs = [tuple(t.cpu().numpy() for t in pkg.Procedure.sample_epoch_to_device(ds, DEV)) for _ in range(2)]
+        out.append(epochs)
+    for e in range(2):
+        for c in range(3):
+            assert np.array_equal(out[0][e][c], out[1][e][c]), (e, c)
+    assert len(out[0][0][0]) == n_users * keep
+    w.configure([])
 
 
 @pytest.mark.parametrize("K", [1, 3])

@@ -29,8 +29,20 @@ def test_library_exports_every_declared_symbol(pkg):
     assert set(pkg._lib.SIGNATURES) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lgcn_abi_version() == 7
+    want = int(re.search(r"#define\s+LGCN_ABI_VERSION\s+(\d+)", open(os.path.join(REPO, "include", "lgcn_hip.h")).read()).group(1))
+    assert lib.lgcn_abi_version() == want == pkg._lib.ABI_VERSION
     assert lib.lgcn_device_available() in (0, 1)
+
+
+def test_graft_entry_build_checks(pkg):
+    """__graft_entry__.build() = compile + check_build(); the checks (ABI version of header, binding and library
+    agree; every declared symbol exported and bound) run here on the library the session already has, and the
+    module's own constants cannot drift from them (round 2 shipped a build() that asserted a stale literal)."""
+    import __graft_entry__ as ge
+    lib = ge.check_build(pkg)
+    assert lib is pkg._lib.load()
+    src = open(ge.__file__).read()
+    assert "lgcn_abi_version() ==" in src and not re.search(r"lgcn_abi_version\(\) == \d", src)
 
 
 def test_glibc_stream_and_randint(pkg):

@@ -151,3 +151,66 @@ def test_row_ranges_partition_and_balance(pkg, lastfm):
         assert np.array_equal(np.sort(own), np.arange(N))
         nnz = np.array([(ip[rr[r, 1]] - ip[rr[r, 0]]) + (ip[rr[r, 3]] - ip[rr[r, 2]]) for r in range(world)], np.float64)
         assert nnz.max() <= 1.3 * nnz.mean() + 2 * np.diff(ip).max()
+
+
+def _comm_fail_worker(rank, world, port, out, case):
+    """The library's communicator cannot be had (rank 0 used to raise before the broadcast the other
+    ranks were already waiting in -> mismatched collectives).  Every rank must come out of _own_communicator_ok()
+    with False, having run the same collective sequence."""
+    import shutil, tempfile
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    pkg = importlib.import_module(PKG_NAME)
+    g = GoldenSet("tiny")
+    work = tempfile.mkdtemp(prefix=f"lgcn_dpfail{rank}")
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(g.dir, f), os.path.join(work, f))
+    w = pkg.world
+    w.configure(["--dataset", "tiny", "--tensorboard", "0", "--layer", str(g.K), "--recdim", str(g.d), "--bpr_batch", str(g.B)])
+    ds = pkg.dataloader.Loader(w.config, path=work)
+    model = pkg.model.LightGCN(w.config, ds)                      # CPU tensors: only the agreement protocol runs
+    lib = pkg._lib.load()
+    calls = {"id": 0, "init": 0}
+    if case == "unique_id" and rank == 0:
+        def bad_id(buf):
+            calls["id"] += 1
+            return 12
+        lib.lgcn_dp_unique_id = bad_id
+        lib.lgcn_dp_available = lambda: 1
+    elif case == "unique_id":
+        lib.lgcn_dp_available = lambda: 1
+    if case == "unavailable":
+        lib.lgcn_dp_available = (lambda: 0) if rank == 1 else (lambda: 1)
+    def no_init(*a):
+        calls["init"] += 1
+        return 12
+    lib.lgcn_dp_init = no_init                                    # must never be entered: it is a collective
+    dp = pkg.parallel.DataParallelBPR(model, w.config, reduce='rows', shard='batch')
+    ok = dp._own_communicator_ok()
+    good = (ok is False) and calls["init"] == 0 and dp._own_communicator_ok() is False
+    if case == "unique_id" and rank == 0:
+        good = good and calls["id"] == 1
+    # shard='rows' without the communicator: a clear error, not a recursion between _step and train_epoch
+    dp2 = pkg.parallel.DataParallelBPR(model, w.config, reduce='rows', shard='rows')
+    u = torch.zeros(4, dtype=torch.int64)
+    try:
+        dp2.stageOne(u, u, u)
+        good = False
+    except RecursionError:
+        good = False
+    except RuntimeError as e:
+        good = good and "row-sharded" in str(e)
+    t = torch.tensor([1 if good else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(out, "w").write(str(int(t.item())))
+    shutil.rmtree(work, ignore_errors=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["unique_id", "unavailable"])
+def test_communicator_failure_falls_back_on_every_rank(tmp_path, case):
+    out = os.path.join(str(tmp_path), "ok.txt")
+    mp.spawn(_comm_fail_worker, args=(2, _free_port(), out, case), nprocs=2, join=True)
+    assert open(out).read() == "1"
