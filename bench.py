@@ -136,6 +136,10 @@ def main():
     ap.add_argument("--dp_shard", default="batch", choices=["batch", "rows"],
                     help="batch: replicated propagation, sharded batch; rows: row-sharded propagation too")
     ap.add_argument("--force_dp", action="store_true", help="use the data-parallel step (RCCL) even at world size 1")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the reference's step, ONE global batch of B triplets sharded over the ranks "
+                         "(SURVEY 8d C4; north_star: 'shards BPR batches'); weak = B triplets PER rank, global batch N*B.  Either "
+                         "way `value` is global optimizer steps/s; triplets/s is reported beside it")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
     a = ap.parse_args()
@@ -167,7 +171,8 @@ def main():
         dist.barrier()
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_plus_1": float(t.item()),
-                              "workload": a.workload, "steps": a.steps, "warmup": a.warmup}))
+                              "workload": a.workload, "steps": a.steps, "warmup": a.warmup, "scaling": a.scaling,
+                              "global_batch": B * world if a.scaling == "weak" else B}))
         dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
@@ -250,7 +255,7 @@ def main():
         return
 
     # triplets for warmup + timed steps, resident in HBM before the timed region
-    Bg = B * world                                   # weak scaling: per-GPU batch fixed
+    Bg = B * world if a.scaling == "weak" else B     # weak: per-GPU batch fixed; strong: the global batch is the reference's B
     need = (a.warmup + a.steps) * Bg
     if ds.trainDataSize <= 4 * need:
         us, ps, ns = [], [], []
@@ -330,15 +335,20 @@ def main():
                    + (" + row-sharded propagation with one all-gather per layer" if a.dp_shard == "rows" else "")
                    + " over RCCL)")
         out = {
-            "metric": f"BPR training steps/sec (one step = K-layer LightGCN propagation + BPR loss + backward + Adam on a batch of {B} triplets per GPU)",
-            "value": steps_per_sec * world, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # `value` = GLOBAL optimizer steps per second in both modes (never multiplied by the world size: with replicated
+            # propagation every rank repeats the 2K-1 SpMMs, so this number is ~flat in N by construction of the algorithm;
+            # what grows under weak scaling is config.triplets_per_sec)
+            "metric": f"BPR training steps/sec (one step = K-layer LightGCN propagation + BPR loss + backward + Adam on a global batch of {Bg} triplets)",
+            "value": steps_per_sec, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32" if a.act_dtype == "fp32" else "f32 accumulate, bf16 activation storage",
             "data": data_kind,
             "config": {"workload": f"{a.workload}: {ds.n_users} users x {ds.m_items} items, {ds.trainDataSize} train "
-                                   f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d}, bpr_batch={B} per GPU",
-                       "global_batch": Bg, "per_gpu_batch": B, "global_steps_per_sec": steps_per_sec,
-                       "triplets_per_sec": steps_per_sec * Bg, "parallelism": par,
+                                   f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d}, bpr_batch={B}",
+                       "global_batch": Bg, "per_gpu_batch": (Bg + world - 1) // world, "global_steps_per_sec": steps_per_sec,
+                       "triplets_per_sec": steps_per_sec * Bg, "batches_of_B_per_sec": steps_per_sec * Bg / B,
+                       "scaling_mode": a.scaling, "multi_gpu_status": "unmeasured on multi-GPU hardware by the builder (1-GPU boxes only)" if world > 1 else "n/a",
+                       "parallelism": par,
                        "act_dtype": a.act_dtype, "xcd_remap": a.xcd_remap, "row_order": a.row_order,
                        "first_loss": first_loss, "last_loss": last_loss, "setup_seconds": setup_s},
             "step_algorithmic_bytes": step_bytes(N, nnz, d, s, K, B),

@@ -112,5 +112,81 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return lib
 
 
+SAMPLING_SRC = os.path.join(PKG_DIR, "csrc", "sampling_module.cpp")
+
+
+def sampling_module_path():
+    import sysconfig
+    return os.path.join(PKG_DIR, "sources", "sampling" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_sampling_module(force=False, verbose=False):
+    """Compile csrc/sampling_module.cpp (pybind11) into sources/sampling<ext>.so: the reference's native plugin as
+    a compiled extension module named `sampling` (sources/sampling.cpp:95-106), a binding over liblgcn_hip.so's C ABI
+    (linked with an $ORIGIN rpath, so the pair moves together).  g++ only -- no hipcc, no GPU.  Returns the path, or
+    None when pybind11 / Python headers are not available (the ctypes binding sampling.py serves the same names)."""
+    import sysconfig
+    try:
+        import pybind11
+    except ImportError:
+        return None
+    out = sampling_module_path()
+    lib = build()
+    stamp = out + ".srchash"
+    h = hashlib.sha256()
+    for f in (SAMPLING_SRC, HEADER):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    want = h.hexdigest()
+    if not force and os.path.exists(out):
+        try:
+            if open(stamp).read().strip() == want:
+                return out
+        except OSError:
+            pass
+    if must_not_build():
+        return out if os.path.exists(out) else None
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    inc_py = sysconfig.get_paths().get("include")
+    if cxx is None or not inc_py or not os.path.exists(os.path.join(inc_py, "Python.h")):
+        return None
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            tmp = f"{out}.tmp.{os.getpid()}"
+            cmd = [cxx, "-O2", "-shared", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-I" + inc_py, "-I" + pybind11.get_include(),
+                   "-I" + os.path.join(REPO_DIR, "include"), SAMPLING_SRC, "-o", tmp,
+                   "-L" + os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, out)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+            with open(stamp, "w") as f:
+                f.write(want)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
+
+
+def load_sampling_module():
+    """Import the compiled `sampling` extension by path -- what utils.py:25-34 does through cppimport."""
+    import importlib.util
+    path = build_sampling_module()
+    if path is None or not os.path.exists(path):
+        raise ImportError("compiled sampling module not available (pybind11 / Python headers / g++ missing)")
+    from . import _lib
+    _lib.load()                       # map liblgcn_hip.so first: ONE library instance, one rand() stream for both bindings
+    spec = importlib.util.spec_from_file_location("sampling", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_sampling_module(force=True, verbose=True))

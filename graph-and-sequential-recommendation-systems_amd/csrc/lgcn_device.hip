@@ -116,15 +116,19 @@ template <typename TI, bool SPARSE> struct Raw;
 template <> struct Raw<float, false> {
     static constexpr int CPL = 4;
     typedef f32x4 T;
-    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
-        return *reinterpret_cast<const T *>((const float *)s.X + (int64_t)col * D + l * 4); }
+    // BIG = false (table under 4 GiB): uniform base + ONE 32-bit byte offset per gather (v_lshl_add_u32, SGPR-base
+    // addressing) instead of a sign extension, a 64-bit shift and a 64-bit add per gathered row
+    template <bool BIG> static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        if (BIG) return *reinterpret_cast<const T *>((const float *)s.X + (int64_t)col * D + l * 4);
+        return *reinterpret_cast<const T *>((const char *)s.X + ((uint32_t)col * (uint32_t)(D * 4) + (uint32_t)(l * 16))); }
     static __device__ __forceinline__ f32x4 cvt(const T &r, float) { return r; }
 };
 template <> struct Raw<bf16_t, false> {
     static constexpr int CPL = 8;
     typedef bf16x8 T;
-    static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
-        return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 8); }
+    template <bool BIG> static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        if (BIG) return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 8);
+        return *reinterpret_cast<const T *>((const char *)s.X + ((uint32_t)col * (uint32_t)(D * 2) + (uint32_t)(l * 16))); }
     static __device__ __forceinline__ f32x8 cvt(const T &r, float) { return __builtin_convertvector(r, f32x8); }
 };
 // SPARSE: the flagged rows of Gs, converted once per step from the fixed-point accumulator to fp32 by k_g32
@@ -150,40 +154,41 @@ template <int D, typename TI, bool SPARSE> struct Geo {
 // Partial sums are combined across the lane groups in a fixed order: deterministic,
 // and identical wherever this function is used.
 // ---------------------------------------------------------------------------------
-// stage one tile of n <= 64 (col,val) pairs held one per lane; returns the staged count
+// stage one tile of n <= 64 (col,val) pairs held one per lane; returns the staged count.  The tile is followed by
+// zero-weight entries (column 0) up to TILE_PAD positions past its end, so that the gather batches below read
+// past-the-end slots WITHOUT a per-gather clamp / compare / select (3 vector instructions per gathered row):
+// positions [cnt, 64) are written here, positions [64, 64 + TILE_PAD) once per wave by tile_pad_init().
+#define TILE_PAD 64           /* >= 4 * NPW of every geometry (d = 32 with a bf16 table: NPW = 16) */
+#define TILE_ST (64 + TILE_PAD)
+__device__ __forceinline__ void tile_pad_init(int2 *stage, int lane) { stage[64 + lane] = make_int2(0, 0); }
 template <bool SPARSE>
 __device__ __forceinline__ int tile_stage(int col, float val, int n, const GatherSrc &src, int lane, int2 *stage) {
     if (!SPARSE) {
-        if (lane < n) stage[lane] = make_int2(col, __float_as_int(val));
+        stage[lane] = lane < n ? make_int2(col, __float_as_int(val)) : make_int2(0, 0);
         return n;
     }
     const bool act = (lane < n) && bit_set(src.bm, col);
     const unsigned long long mask = __ballot(act);
-    if (act) {
-        const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        stage[pos] = make_int2(col, __float_as_int(val));
-    }
-    return __popcll(mask);
+    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    const int cnt = __popcll(mask);
+    // flagged entries at their compacted position, the others behind them as zero-weight padding: all 64 slots written
+    stage[act ? below : cnt + (lane - below)] = act ? make_int2(col, __float_as_int(val)) : make_int2(0, 0);
+    return cnt;
 }
 
-// One batch of U gathers per lane: entries j0+g, j0+g+NPW, ... of the staged tile.
-template <int D, typename TI, bool SPARSE, int U>
-__device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt, const GatherSrc &src, int lane,
+// One batch of U gathers per lane: entries j0+g, j0+g+NPW, ... of the staged tile (past the end: zero-weight padding).
+template <int D, typename TI, bool SPARSE, int U, bool BIG>
+__device__ __forceinline__ void gather_batch(const int2 *stage, int j0, const GatherSrc &src, int lane,
                                              typename Geo<D, TI, SPARSE>::Acc &acc) {
     typedef Geo<D, TI, SPARSE> G;
     typedef Raw<TI, SPARSE> R;
     const int g = lane / G::LPR, l = lane % G::LPR;
     int2 cv[U]; typename R::T x[U];
+    const int2 *p = stage + j0 + g;
 #pragma unroll
-    for (int u = 0; u < U; u++) {                                        // all LDS reads first
-        // past-the-end slots re-read the tile's last entry with weight 0: every gather is
-        // unconditional (a predicated load makes hipcc wait for the previous one)
-        const int e = j0 + g + u * G::NPW;
-        cv[u] = stage[min(e, cnt - 1)];
-        if (e >= cnt) cv[u].y = 0;
-    }
+    for (int u = 0; u < U; u++) cv[u] = p[u * G::NPW];                   // all LDS reads first (one base, immediate offsets)
 #pragma unroll
-    for (int u = 0; u < U; u++) x[u] = R::load(src, cv[u].x, D, l);      // U gathers in flight
+    for (int u = 0; u < U; u++) x[u] = R::template load<BIG>(src, cv[u].x, D, l);      // U gathers in flight
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(x[u], src.div);
@@ -192,19 +197,20 @@ __device__ __forceinline__ void gather_batch(const int2 *stage, int j0, int cnt,
 // Gather-accumulate the staged tile.  The batch depth follows the (wave-uniform) number of staged
 // neighbours instead of always issuing the deepest batch: a 64-lane gather instruction costs the
 // CU's address path the same whether 1 or all of its row slots are useful.
-template <int D, typename TI, bool SPARSE, int UCAP = LGCN_GATHER_U>
+template <int D, typename TI, bool SPARSE, bool BIG, int UCAP = LGCN_GATHER_U>
 __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const GatherSrc &src, int lane,
                                             typename Geo<D, TI, SPARSE>::Acc &acc) {
     constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 4 : UCAP;
+    static_assert(4 * NPW <= TILE_PAD, "the padding behind a tile must cover the deepest batch's overshoot");
 #ifdef LGCN_EXP_NO_GATHER
     return;
 #endif
     cnt = __builtin_amdgcn_readfirstlane(cnt);
     int j = 0;
-    if (UMAX >= 8) for (; cnt - j > 4 * NPW; j += 8 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 8 ? 8 : UMAX)>(stage, j, cnt, src, lane, acc);
-    if (UMAX >= 4) for (; cnt - j > 2 * NPW; j += 4 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 4 ? 4 : UMAX)>(stage, j, cnt, src, lane, acc);
-    for (; cnt - j > NPW; j += 2 * NPW) gather_batch<D, TI, SPARSE, 2>(stage, j, cnt, src, lane, acc);
-    if (cnt - j > 0) gather_batch<D, TI, SPARSE, 1>(stage, j, cnt, src, lane, acc);
+    if (UMAX >= 8) for (; cnt - j > 4 * NPW; j += 8 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 8 ? 8 : UMAX), BIG>(stage, j, src, lane, acc);
+    if (UMAX >= 4) for (; cnt - j > 2 * NPW; j += 4 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 4 ? 4 : UMAX), BIG>(stage, j, src, lane, acc);
+    for (; cnt - j > NPW; j += 2 * NPW) gather_batch<D, TI, SPARSE, 2, BIG>(stage, j, src, lane, acc);
+    if (cnt - j > 0) gather_batch<D, TI, SPARSE, 1, BIG>(stage, j, src, lane, acc);
 }
 
 // Sum over the lanes that hold the same columns (lane % LPR equal): every lane ends with the full
@@ -251,11 +257,12 @@ struct PackedSrc {
     __device__ __forceinline__ int2 at(int64_t i) const { return pk[i]; }
 };
 
-template <int D, typename TI, bool SPARSE, typename ES>
+template <int D, typename TI, bool SPARSE, bool BIG, typename ES>
 __device__ __forceinline__ typename Geo<D, TI, SPARSE>::Acc
 row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int lane, int2 *stage) {
     typedef Geo<D, TI, SPARSE> G;
     typename G::Acc acc = zerov<G::CPL>();
+    tile_pad_init(stage, lane);
     // the next tile's (col,val) pairs are in flight while this tile gathers
     int2 cv = make_int2(0, 0);
     if (start + lane < end) cv = es.at(start + lane);
@@ -264,7 +271,7 @@ row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int l
         const int cnt = tile_stage<SPARSE>(cv.x, __int_as_float(cv.y), n, src, lane, stage);
         __builtin_amdgcn_wave_barrier();
         if (base + 64 + lane < end) cv = es.at(base + 64 + lane);
-        tile_gather<D, TI, SPARSE>(stage, cnt, src, lane, acc);
+        tile_gather<D, TI, SPARSE, BIG>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
     }
     return reduce_groups<G::LPR>(acc);
@@ -327,6 +334,7 @@ struct SpmmArgs {
     const int4 *rowinfo;          // short rows of the slices, padded per slice: (row | -1, first entry in the stream, count, 0)
     LongPlan lp; SlicePlan sp;
     const void *X; void *Y;
+    int64_t n_rows;               // rows of X (picks 32- or 64-bit gather offsets)
     long long *G64; uint32_t *bitmap; float div;   // sparse gradient rows (fixed point), K+1
     const float *G32;             // their fp32 copy Gs = G64 / 2^50 / (K+1), valid on the flagged rows (k_g32)
     float *P; float *M; float *V;
@@ -444,24 +452,22 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 #ifndef SPMM_U
 #define SPMM_U 8              /* gathers in flight per lane in the short-row path */
 #endif
-// One batch of U gathers of a lane group walking ITS OWN row: entries u0 .. u0+U-1 of the group's staged
-// row (past the row's end: zero-weight re-read of its last entry -- unconditional loads, see gather_batch).
-template <int D, typename TI, bool SPARSE, int U, int GPR = 1, bool PRE = false>
-__device__ __forceinline__ void pack_batch(const int2 *mystage, int u0, int mycnt, int last, const GatherSrc &src, int l,
-                                           typename Geo<D, TI, SPARSE>::Acc &acc, int sub = 0,
-                                           const SpmmArgs *a = nullptr, int64_t off = -1, bool final_batch = false,
-                                           AdamPre<Geo<D, TI, SPARSE>::CPL> *pre = nullptr) {
+// One batch of U gathers of a lane group walking ITS OWN row: the next U of its entries, p[0], p[GPR], ... (GPR lane
+// groups share a row and take alternate entries).  Past the row's end the staged row continues with zero-weight
+// entries (written once per pack), so a gather costs its address, its load and its multiply-adds and nothing else
+// (before: clamp, select, compare, select, LDS address and a 64-bit address per gathered row -- 9 of the 12 / 21 vector
+// instructions per fp32 / bf16 gather; loads are unconditional either way: a predicated load makes hipcc wait).
+template <int D, typename TI, bool SPARSE, int U, int GPR, bool PRE, bool BIG>
+__device__ __forceinline__ void pack_batch(const int2 *p, const GatherSrc &src, int l,
+                                           typename Geo<D, TI, SPARSE>::Acc &acc,
+                                           const SpmmArgs *a, int64_t off, bool final_batch,
+                                           AdamPre<Geo<D, TI, SPARSE>::CPL> *pre) {
     typedef Raw<TI, SPARSE> R;
     int2 cv[U]; typename R::T xr[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int e = u0 + u;
-        // GPR lane groups share a row: this group takes entries sub, sub+GPR, ... (entry 0 is always valid)
-        cv[u] = mystage[GPR == 1 ? min(e, last) : (mycnt > 0 ? sub + GPR * min(e, last) : 0)];
-        if (e >= mycnt) cv[u].y = 0;
-    }
+    for (int u = 0; u < U; u++) cv[u] = p[u * GPR];
 #pragma unroll
-    for (int u = 0; u < U; u++) xr[u] = R::load(src, cv[u].x, D, l);
+    for (int u = 0; u < U; u++) xr[u] = R::template load<BIG>(src, cv[u].x, D, l);
     if (PRE && final_batch && off >= 0) {       // the pack's last gathers are in flight: Adam's operands ride the same round trip
         constexpr int C = Geo<D, TI, SPARSE>::CPL;
         pre->p = loadv<C>(a->P + off); pre->m = loadv<C>(a->M + off); pre->v = loadv<C>(a->V + off);
@@ -513,7 +519,7 @@ template <int LPR, int GPR> __device__ __forceinline__ float sum_row_groups(floa
     return v;
 }
 
-template <int D, typename TI, typename TO, int MODE>
+template <int D, typename TI, typename TO, int MODE, bool BIG>
 __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) == 4) ? SPMM_MIN_WAVES_ADAM : SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr bool SP = (MODE & M_SPARSE) != 0;
     typedef Geo<D, TI, SP> G;
@@ -524,9 +530,12 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
     static_assert(GPR == 1 || GPR == 2 || GPR == 4, "one, two or four lane groups per row");
     static_assert(LPR * GPR <= 64 && (GPR == 1 || LPR >= 4), "lane groups of a row must fit the wave");
     constexpr int PACKS = PackGeo<RPK>::PACKS, RPW = PackGeo<RPK>::RPW, RPB = PackGeo<RPK>::RPB;
-    constexpr int ST = 66;        // stage row stride (entries): lane groups reading the same position of different rows hit different banks
+    // stage row stride (entries): a row's <= 64 entries + the zero-weight tail the deepest batch may read (3 per lane
+    // group of the row); lane groups reading the same position of different rows hit different banks (76 * 2 mod 64 = 24)
+    constexpr int ST = 76;
+    static_assert(64 + 3 * GPR <= ST, "staged row + padding");
     constexpr int U = SP ? SPMM_U_SP : SPMM_U;
-    __shared__ int2 stage_lds[SPMM_WPB][(RPK * ST > 64 ? RPK * ST : 64)];
+    __shared__ int2 stage_lds[SPMM_WPB][(RPK * ST > TILE_ST ? RPK * ST : TILE_ST)];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
@@ -557,7 +566,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
         const int64_t row = a.lp.long_row[o];
         const int nch = a.lp.long_nch[o];
         const bool rflag = (MODE & M_ADDG) ? bit_set(a.bitmap, (int)row) : false;
-        Acc acc = row_gather<D, TI, SP>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
+        Acc acc = row_gather<D, TI, SP, BIG>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
         if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
             if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc, rflag);
             return;
@@ -632,8 +641,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
             if (it * 64 < tot) { const int e = it * 64 + lane; if (e < tot) cvr[it] = a.pk[base + e]; }
         }
         const int myr = g / GPR, sub = g % GPR;      // this lane group's row of the pack, and its share of it
-        const int mylen = __shfl(my_n, myr);
-        int mycnt = GPR == 1 ? mylen : max(0, (mylen - sub + GPR - 1) / GPR), maxcnt = 0;
+        int maxcnt = 0;
         if (!SP) {
 #pragma unroll
             for (int it = 0; it < RPK; it++) {
@@ -648,9 +656,13 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
                     if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
                 }
             }
-            if (lane < RPK && my_n == 0) stage[lane * ST] = make_int2(0, 0);      // a valid column for the padding reads of an empty row
 #pragma unroll
             for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, (off[r + 1] - off[r] + GPR - 1) / GPR);
+            // zero-weight tail of every row up to what the longest row's batches read (see pack_batch)
+            const int padto = GPR * (maxcnt + 3);
+#pragma unroll
+            for (int r = 0; r < RPK; r++)
+                for (int q = off[r + 1] - off[r] + lane; q < padto; q += 64) stage[r * ST + q] = make_int2(0, 0);
         } else {
             // keep only the neighbours whose row is flagged.  The bitmap words of ALL the pack's entries are
             // fetched in one round trip straight from the registers the stream landed in, and every entry is
@@ -682,18 +694,16 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
                     }
                 }
             }
-            mycnt = cntr[0];
-            int lanecnt = cntr[0];       // count of row `lane` (lanes < RPK)
-#pragma unroll
-            for (int k = 1; k < RPK; k++) { mycnt = myr == k ? cntr[k] : mycnt; lanecnt = lane == k ? cntr[k] : lanecnt; }
-            if (lane < RPK && lanecnt == 0) stage[lane * ST] = make_int2(0, 0);       // a valid column for the padding reads
 #pragma unroll
             for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, cntr[r]);
+            const int padto = GPR * (maxcnt + 3);
+#pragma unroll
+            for (int r = 0; r < RPK; r++)
+                for (int q = cntr[r] + lane; q < padto; q += 64) stage[r * ST + q] = make_int2(0, 0);
         }
         __builtin_amdgcn_wave_barrier();
         maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
-        const int2 *mystage = stage + myr * ST;
-        const int last = max(mycnt - 1, 0);
+        const int2 *mystage = stage + myr * ST + sub;
         Acc acc = zerov<C>();
         // batch depth follows the pack's longest row (8 / 4 / 2 / 1 gathers per lane): a padded gather costs
         // the address path as much as a useful one
@@ -704,7 +714,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
         AdamPre<C> pre; pre.have = false;
         const int64_t poff = (PRE && mrow >= 0 && sub == 0) ? (int64_t)mrow * D + l * C : -1;
         int u0 = 0;
-#define PACK_BATCH(UU) pack_batch<D, TI, SP, UU, GPR, PRE>(mystage, u0, mycnt, last, src, l, acc, sub, &a, poff, maxcnt - u0 <= UU, &pre)
+#define PACK_BATCH(UU) pack_batch<D, TI, SP, UU, GPR, PRE, BIG>(mystage + GPR * u0, src, l, acc, &a, poff, maxcnt - u0 <= UU, &pre)
         if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) PACK_BATCH((U >= 8 ? 8 : U));
         if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) PACK_BATCH((U >= 4 ? 4 : U));
         for (; maxcnt - u0 > 1; u0 += 2) PACK_BATCH(2);
@@ -860,7 +870,7 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
 #endif
 // units u_first, u_first + 4, ... of the row [start, start + n): one wave's share of a slot row.  The next
 // tile's (col,val) pairs are in flight while this tile gathers, across the unit boundaries too.
-template <int D, typename TG, typename ES>
+template <int D, typename TG, bool BIG, typename ES>
 __device__ __forceinline__ typename Geo<D, TG, false>::Acc
 units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &src, int lane, int2 *stage) {
     typedef Geo<D, TG, false> G;
@@ -878,7 +888,7 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
         if (tn % UT == 0) tn += 3 * UT;
         const bool more = tn < ntiles;
         if (more && tn * 64 + lane < n) cv = es.at(start + tn * 64 + lane);
-        tile_gather<D, TG, false, TRIPLET_U>(stage, cnt, src, lane, acc);
+        tile_gather<D, TG, false, BIG, TRIPLET_U>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
         if (!more) break;
         t = tn;
@@ -887,7 +897,7 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
 }
 
 // TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
-template <int D, typename TG, typename TI>
+template <int D, typename TG, typename TI, bool BIG>
 __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[4][D], float (*base)[D]) {
     typedef Geo<D, TG, false> G;
     constexpr int C = G::CPL, LPR = G::LPR, UN = 64 * ROWS_UNIT_TILES;
@@ -916,13 +926,14 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
         }
     }
     GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
+    tile_pad_init(stage, threadIdx.x & 63);
     bool any = (w == 0 || w == 3);
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {                       // (not unrolled: three inlined copies of the gather loop cost 20 VGPRs)
         const int stc = c == 0 ? st0 : (c == 1 ? st1 : st2), nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
         const int u0 = (w - c + 4) & 3, units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
         if (u0 < units) {
-            const typename G::Acc x = units_gather<D, TG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
+            const typename G::Acc x = units_gather<D, TG, BIG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
             if (lane < LPR) storev<C>(&part[c][w][lane * C], x);
             any = true;
         }
@@ -951,17 +962,17 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
     triplet_loss_regs<D>(a, b, lane, e[0], e[1], e[2]);
 }
 
-template <int D, typename TI>
+template <int D, typename TI, bool BIG>
 __global__ void __launch_bounds__(256, sizeof(TI) == 4 ? 8 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
-    __shared__ int2 stage_lds[4][64];
+    __shared__ int2 stage_lds[4][TILE_ST];
     __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
     __shared__ float base_lds[3][D];
     // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
         a.stale_bitmap[i] = 0u;
     int2 *stage = stage_lds[threadIdx.x >> 6];
-    if (a.K == 1) triplet_body<D, float, TI>(a, a.X0, stage, part_lds, base_lds);
-    else triplet_body<D, TI, TI>(a, a.Xl[a.K - 1], stage, part_lds, base_lds);
+    if (a.K == 1) triplet_body<D, float, TI, BIG>(a, a.X0, stage, part_lds, base_lds);
+    else triplet_body<D, TI, TI, BIG>(a, a.Xl[a.K - 1], stage, part_lds, base_lds);
 }
 
 // The same when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row reads per slot,
@@ -1090,6 +1101,9 @@ __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, 
 // ---------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------
+// gathered tables of 4 GiB or more need 64-bit offsets (priced at the fp32 row size whatever the table type)
+static inline bool big_table(int64_t n_rows, int d) { return n_rows * (int64_t)d * 4 >= (1ll << 32); }
+
 template <int D, typename TI, typename TO, int MODE>
 static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     constexpr int RPB = PackGeo<RowGeo<D, TI, (MODE & M_SPARSE) != 0>::RPK>::RPB;
@@ -1101,7 +1115,8 @@ static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     }
     if (a.remap) grid = widest * XCDS;
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
+    if (big_table(a.n_rows, D)) hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE, true>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
+    else hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE, false>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
 }
 
 template <int D, int MODE>
@@ -1376,7 +1391,7 @@ extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
 
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
-    a.pk = g->pk; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp;
+    a.pk = g->pk; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp; a.n_rows = g->n_rows;
     return a;
 }
 
@@ -1608,8 +1623,11 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
             const unsigned gd = (unsigned)((B_local + tpb - 1) / tpb);
             if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_triplet_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
-        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float>), dim3(B_local), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_triplet<D, bf16_t>), dim3(B_local), dim3(256), 0, st, a);
+        } else if (big_table(x->N, D)) {
+            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, true>), dim3(B_local), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_triplet<D, bf16_t, true>), dim3(B_local), dim3(256), 0, st, a);
+        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, false>), dim3(B_local), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_triplet<D, bf16_t, false>), dim3(B_local), dim3(256), 0, st, a);
     });
     return 0;
 }

@@ -25,6 +25,15 @@ except Exception as _e:           # library missing: say so (the reference falls
     sample_ext = False
 
 
+def compiled_sampling_module():
+    """The same plugin as a COMPILED extension module named `sampling` (csrc/sampling_module.cpp -> sources/sampling<ext>.so,
+    pybind11), loaded by path exactly as utils.py:25-34 loads the reference's cppimport build.  It binds the same C ABI
+    as `sampling` above -- one library instance, ONE rand() stream shared by both.  Raises ImportError if it cannot be
+    built here (no pybind11 / Python headers / g++); the ctypes binding above does not need it."""
+    from . import build as _build
+    return _build.load_sampling_module()
+
+
 class _AdamView(optim.Adam):
     """torch.optim.Adam whose state tensors are views of the fused kernel's m/v tables, so
     `bpr.opt` keeps the reference's surface (param_groups[0]['lr'], state_dict(),

@@ -26,6 +26,15 @@ def test_bench_self_launches_two_ranks():
     j = json.loads(lines[0])
     assert j["dry_run"] and j["n_gpus"] == 2 and j["max_rank_plus_1"] == 2.0
     assert j["steps"] == 7 and j["warmup"] == 2 and j["workload"] == "amazon-book-shaped"
+    # default = strong scaling: the reference's ONE global batch of 2048 is sharded
+    assert j["scaling"] == "strong" and j["global_batch"] == 2048
+
+
+def test_bench_weak_scaling_flag():
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "weak"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "weak" and j["global_batch"] == 2 * 2048 and j["n_gpus"] == 2
 
 
 def test_bench_single_rank_and_mismatch():

@@ -213,8 +213,26 @@ def test_c5_full_shape(pkg, oracle):
         assert int((delta.amax(1) > 0).sum()) > 3 * B                     # and reaches far more rows than the batch names
         assert float(delta[n_users + top_item].max()) > 0
         del delta
+        rows_on2, loss_on2, chk_on2, smp_on2 = one_step(act, 0)            # the same step again: bit for bit (fixed-point scatter)
+        assert rows_on2 == rows_on and np.array_equal(loss_on, loss_on2) and torch.equal(chk_on, chk_on2) and torch.equal(smp_on, smp_on2)
         rows_off, loss_off, chk_off, smp_off = one_step(act, -1)
         assert rows_off == 0
         assert np.abs(loss_on - loss_off).max() <= 2e-7, (act, loss_on, loss_off)
-        assert float((chk_on - chk_off).abs().max()) <= 1e-6 and float((smp_on - smp_off).abs().max()) <= 1e-6
+        # Parameters: Adam's first step is p -= lr * g / (|g| + eps), which amplifies a difference in g by up to lr / eps = 1e5
+        # where |g| <~ eps (most rows of this graph: they are 2-3 hops from the batch).  Compare in GRADIENT space: invert
+        # the step, g = eps * u / (lr - |u|) with u = E0 - p, where that is well conditioned (|u| <= 0.9 lr).
+        for got_on, got_off, ref0, what in ((chk_on, chk_off, E0[chk_t], "random rows"), (smp_on, smp_off, E0[sample_t], "hub + sampled rows")):
+            u_on, u_off = (ref0 - got_on).double(), (ref0 - got_off).double()
+            ok = (u_on.abs() <= 0.9 * lr) & (u_off.abs() <= 0.9 * lr)
+            g_on, g_off = 1e-8 * u_on / (lr - u_on.abs()), 1e-8 * u_off / (lr - u_off.abs())
+            dg = (g_on - g_off).abs()[ok]
+            scale = torch.maximum(g_on.abs(), g_off.abs())[ok]
+            big = (got_on - got_off).abs()
+            print(f"[c5 {act} {what}] max |dp| {float(big.max()):.3e}; invertible {float(ok.double().mean()):.4f}; "
+                  f"max |dg| {float(dg.max()):.3e}; max |dg|/(|g|+1e-10) {float((dg / (scale + 1e-10)).max()):.3e}; "
+                  f"elements with |dp| > 1e-6: {int((big > 1e-6).sum())} of {big.numel()}")
+            # the hub rows' fp32 summation order (one workgroup's four accumulator chains vs 391 chunks) moves their mean rows by
+            # ~1e-6 relative; through gb = 1/B that is <= 1e-9 on any gradient element
+            assert float(dg.max()) <= 2e-9, (act, what, float(dg.max()))
+            assert float(big.max()) <= 2.0 * lr
     m._drop_device_state()

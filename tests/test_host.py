@@ -86,6 +86,19 @@ def test_loader_and_graph_bit_exact(pkg, tiny, lastfm, tmp_path):
         assert sum(len(v) for v in td.values()) == len(g.test_user)
 
 
+def test_compiled_sampling_module_matches_reference_plugin(tmp_path):
+    """The pybind11 extension module `sampling` (csrc/sampling_module.cpp, loaded BY PATH as utils.py:25-34 loads the
+    reference's cppimport build): the reference's four names and docstrings, int32 outputs of the reference's shapes,
+    rows identical to the ones the reference's own compiled plugin produced (tiny fixture), one rand() stream shared
+    with the ctypes binding, list-of-arrays and CSR-tuple forms, ValueError where the reference dies with SIGFPE.
+    Runs in a process of its own: two extension modules called `sampling` (this one and the reference's build under
+    oracle/_ref that test_sampler_vs_compiled_reference_and_oracle imports) cannot live in one interpreter."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "sampling_module_check.py"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_sampler_cpp_matches_golden(pkg, tiny, tmp_path):
     ds = _load(pkg, tiny, tmp_path)
     pkg.sampling.seed(2020)
