@@ -73,6 +73,7 @@ SIGNATURES = {
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),
     "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lgcn_dp_init_loopback": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lgcn_dp_destroy": (None, [_vp]),
     "lgcn_dp_world": (C.c_int, [_vp]),
     "lgcn_dp_rank": (C.c_int, [_vp]),

@@ -1898,8 +1898,8 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
     if (reduce == LGCN_DP_ROW_SHARDED && !row_ranges) { lgcn_set_error("lgcn_train_epoch_dp: row_ranges missing"); return 3; }
     if (reduce != LGCN_DP_DENSE && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
     if (B_global <= 0 || B_global > x->c.max_batch) { lgcn_set_error("lgcn_train_epoch_dp: batch size out of range"); return 3; }
-    const RcclApi *api = lgcn_rccl();
-    if (!api) return 12;
+    const RcclApi *api = dp->api;             // RCCL, or the in-process loopback of the tests
+    if (!api) { lgcn_set_error("lgcn_train_epoch_dp: communicator without collectives"); return 12; }
     hipStream_t st = (hipStream_t)stream;
     const int world = dp->world, rank = dp->rank;
     LoopScope scope(x);

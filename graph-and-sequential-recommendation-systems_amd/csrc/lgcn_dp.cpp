@@ -84,15 +84,15 @@ extern "C" int lgcn_dp_init(const void *id128, int world, int rank, lgcn_dp **ou
     std::memcpy(&id, id128, sizeof id);
     ncclResult_t r = api->CommInitRank(&dp->comm, world, id, rank);     // on the calling thread's current HIP device
     if (r != ncclSuccess) { delete dp; return rccl_fail(api, "ncclCommInitRank", r); }
-    dp->world = world; dp->rank = rank;
+    dp->world = world; dp->rank = rank; dp->api = api; dp->loopback = false;
     *out = dp;
     return 0;
 }
 
 extern "C" void lgcn_dp_destroy(lgcn_dp *dp) {
     if (!dp) return;
-    const RcclApi *api = lgcn_rccl();
-    if (api) (void)api->CommDestroy(dp->comm);
+    if (dp->loopback) lgcn_dp_loopback_release(dp);
+    else if (dp->api) (void)dp->api->CommDestroy(dp->comm);
     delete dp;
 }
 

@@ -25,5 +25,8 @@ const RcclApi *lgcn_rccl();      // nullptr (+ error text) if RCCL cannot be fou
 struct lgcn_dp {
     ncclComm_t comm;
     int world, rank;
+    const RcclApi *api;      // the collectives this communicator runs on: RCCL (lgcn_dp.cpp) or the in-process loopback
+    bool loopback;
 };
+void lgcn_dp_loopback_release(lgcn_dp *dp);      // lgcn_dp_loopback.hip
 #endif

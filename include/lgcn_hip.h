@@ -266,6 +266,12 @@ typedef struct lgcn_dp lgcn_dp;   /* opaque */
 int lgcn_dp_available(void);                         /* 1 if RCCL could be resolved */
 int lgcn_dp_unique_id(void *id128);
 int lgcn_dp_init(const void *id128, int world, int rank, lgcn_dp **out);   /* on the current HIP device */
+/* TEST HOOK, no RCCL involved: `world` communicators for `world` THREADS OF THIS PROCESS on the current device
+ * (out[world]; destroy each with lgcn_dp_destroy).  Their collectives meet on a host barrier and move the blocks
+ * with hipMemcpyAsync on the calling rank's stream, so lgcn_train_epoch_dp's world > 1 control flow can run -- and
+ * be compared bit for bit with the single-GPU epoch -- on a one-GPU machine: every thread calls
+ * lgcn_train_epoch_dp with its own context, tables, stream and communicator.  Synchronous by construction. */
+int lgcn_dp_init_loopback(int world, lgcn_dp **out);
 void lgcn_dp_destroy(lgcn_dp *dp);
 int lgcn_dp_world(const lgcn_dp *dp);
 int lgcn_dp_rank(const lgcn_dp *dp);

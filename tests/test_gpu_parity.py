@@ -317,6 +317,68 @@ def test_dp_rows_one_model_per_rank(pkg, tiny, tmp_path, world, local):
         m.check_device_errors()
 
 
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["rows", "dense", "row_sharded"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_dp_epoch_c_loop_world_gt_1_loopback(pkg, tiny, lastfm, tmp_path, world, mode, act):
+    """lgcn_train_epoch_dp ITSELF at world > 1 on one GPU: W threads of this process, each with its own model, context,
+    stream and loopback communicator (lgcn_dp_init_loopback: the collectives meet on a host barrier and move the blocks
+    with hipMemcpyAsync -- no RCCL, no second process), run the C loop of a whole epoch in all three exchange modes:
+    gradient-row all-gather (LocalScope: own rows added in part 1), dense all-reduce of the fixed-point table, and
+    row-sharded propagation (rs_exchange's grouped in-place broadcasts, owned-row plans).  T is not a multiple of the
+    batch and the last batch leaves trailing ranks EMPTY.  Every rank must end bit for bit where the single-GPU
+    epoch ends, with the same per-step losses."""
+    import threading
+    g = tiny if mode != "row_sharded" or world < 4 else lastfm
+    rng = np.random.Generator(np.random.PCG64(17 * world + len(mode)))
+    B = 48
+    T = 3 * B + (2 if world > 2 else 1)                       # last global batch: 1-2 triplets -> trailing ranks get none
+    u = rng.integers(0, g.n_users, T); p = rng.integers(0, g.m_items, T); n = rng.integers(0, g.m_items, T)
+    u[5] = u[40]; p[7] = p[30]                                 # the same rows named by different ranks' shards
+    U, P, Nn = (_dev(x, torch.int32) for x in (u, p, n))
+    ds, ref = _make_model(pkg, g, tmp_path, act_dtype=act, B=B)
+    want_loss = ref.fused_epoch(U, P, Nn, B).cpu().numpy()
+    want = ref._table.cpu().numpy().view(np.uint32)
+    L, lib = pkg._lib, pkg._lib.load()
+    models = [_make_model(pkg, g, tmp_path, act_dtype=act, B=B)[1] for _ in range(world)]
+    par = pkg.parallel
+    ranges = par.row_ranges(models[0]._adj.indptr, models[0].n_users, world) if mode == "row_sharded" else None
+    states = [m._state(max_batch=B, need_ctx=True, dp_world=world,
+                       row_subset=par.owned_rows(ranges, r) if ranges is not None else None) for r, m in enumerate(models)]
+    comms = (C.c_void_p * world)()
+    L.check(lib.lgcn_dp_init_loopback(world, comms), "loopback")
+    code = {"rows": 0, "dense": 1, "row_sharded": 2}[mode]
+    steps = (T + B - 1) // B
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    gathered = [torch.empty(world * par.block_numel(B, world, g.d), device=DEV) for _ in range(world)]
+    losses = [torch.empty(steps, 3, device=DEV) for _ in range(world)]
+    rr = np.ascontiguousarray(ranges, np.int64) if ranges is not None else None
+    torch.cuda.synchronize()
+    rcs, errs = [None] * world, [None] * world
+
+    def rank_main(r):
+        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, code,
+                                         L.npp(rr) if rr is not None else None, L.tp(gathered[r]), L.tp(losses[r]),
+                                         C.c_void_p(streams[r].cuda_stream))
+        if rcs[r]:
+            errs[r] = lib.lgcn_last_error()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank did not come back from lgcn_train_epoch_dp"
+    torch.cuda.synchronize()
+    assert rcs == [0] * world, (rcs, errs)
+    for r, m in enumerate(models):
+        assert np.array_equal(losses[r].cpu().numpy(), want_loss), (mode, world, r)
+        assert np.array_equal(m._table.cpu().numpy().view(np.uint32), want), (mode, world, r)
+        assert not bool(m._dev['G64'].any())
+        m.check_device_errors()
+    for r in range(world):
+        lib.lgcn_dp_destroy(comms[r])
+
+
 def test_out_of_range_ids_are_flagged_not_faulting(pkg, tiny, tmp_path):
     ds, m = _make_model(pkg, tiny, tmp_path)
     before = m._table.clone()
