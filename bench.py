@@ -127,7 +127,6 @@ def main():
     ap.add_argument("--xcd_remap", type=int, default=1)
     ap.add_argument("--dense_last", default="auto", choices=["auto", "0", "1"], help="last forward layer: on the batch rows only (0) or densely (1)")
     ap.add_argument("--row_order", default=None, choices=["natural", "rcm", "cocluster", "xcd"])
-    ap.add_argument("--hot_plan", type=int, default=1, help="0: bypass the hot-column plan of heavy-tailed graphs (A/B)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
     ap.add_argument("--spmm_only", action="store_true", help="only the dominant-kernel loop (profiling helper)")
@@ -191,7 +190,7 @@ def main():
     w = pkg.world
     w.configure(["--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B), "--act_dtype", a.act_dtype,
                  "--xcd_remap", str(a.xcd_remap), "--row_order", a.row_order, "--tensorboard", "0",
-                 "--dataset", a.workload, "--dense_last", a.dense_last, "--hot_plan", str(a.hot_plan)])
+                 "--dataset", a.workload, "--dense_last", a.dense_last])
     import io
     import contextlib
     t_setup = time.perf_counter()
@@ -244,10 +243,7 @@ def main():
         bytes_spmm = spmm_bytes(N, nnz, d, s)
         achieved = bytes_spmm / t_spmm / 1e9
         traffic, note = read_traffic(f"{a.workload}:{a.act_dtype}:k_spmm", lib_hash)
-        n_hot, cover = model._state()['graph'].hot_info()
-        hot_on = n_hot > 0 and a.hot_plan
-        return {"bound": "hbm", "kernel": f"{'k_spmm_hot' if hot_on else 'k_spmm'}<{d},{'float' if adt == 0 else 'bf16'}> (dense CSR-SpMM layer)",
-                "hot_rows_in_lds": n_hot if hot_on else 0, "hot_gather_share": cover if hot_on else 0.0,
+        return {"bound": "hbm", "kernel": f"k_spmm<{d},{'float' if adt == 0 else 'bf16'}> (dense CSR-SpMM layer)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": note, "algorithmic_bytes_per_launch": bytes_spmm,
                 "avg_launch_us": t_spmm * 1e6, "gather_bytes_upper_bound": nnz * d * s}

@@ -52,8 +52,6 @@ SIGNATURES = {
     "lgcn_build_norm_adj": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgcn_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, C.POINTER(_vp)]),
     "lgcn_graph_destroy": (None, [_vp]),
-    "lgcn_graph_set_hot": (C.c_int, [_vp, C.c_int]),
-    "lgcn_graph_hot_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "lgcn_spmm_csr": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]),
     "lgcn_propagate_mean": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "lgcn_apply_perm": (C.c_int, [_vp, C.c_int, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
@@ -208,17 +206,6 @@ class Graph:
         y = torch.empty(x.shape, dtype=torch.bfloat16 if yd == BF16 else torch.float32, device=x.device)
         check(load().lgcn_spmm_csr(self.handle, tp(x), xd, tp(y), yd, int(x.shape[1]), current_stream()), "lgcn_spmm_csr")
         return y
-
-    def hot_info(self):
-        """(H, cover): rows of X the hot-column plan keeps in LDS (0: the graph has no such plan) and the share of
-        all gathers they take."""
-        n, c = C.c_int32(0), C.c_double(0.0)
-        check(load().lgcn_graph_hot_info(self.handle, C.byref(n), C.byref(c)), "lgcn_graph_hot_info")
-        return int(n.value), float(c.value)
-
-    def set_hot(self, on):
-        """Use (default) or bypass the hot-column plan in later launches on this graph."""
-        check(load().lgcn_graph_set_hot(self.handle, 1 if on else 0), "lgcn_graph_set_hot")
 
     def close(self):
         if getattr(self, "handle", None):

@@ -345,15 +345,6 @@ struct SpmmArgs {
     const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
-    // hot-column plan (k_spmm_hot; heavy-tailed graphs only): the H most gathered rows of X are copied into LDS by every
-    // persistent workgroup and the entries that name them are read from there, not gathered
-    const int2 *pk_cold;          // (col, val bits) of the planned rows' other entries, plan order of the hot plan
-    const int2 *pk_hot;           // (hot slot, val bits) of the planned rows' hot entries, plan order
-    const int4 *rowinfo_hot;      // short rows: (row | -1, first cold entry in pk, cold count | hot count << 8, first hot entry in pk_hot)
-    const int4 *chunks_cold;      // long rows' chunks, same slots as lp.chunks: (index into long_row | -1, first, end in pk, ordinal)
-    const int2 *chunks_hot;       //   and their hot entries: (first, end) in pk_hot
-    const int32_t *hot_cols;      // [n_hot] the hot rows of X, hottest first
-    int32_t n_hot;
 };
 
 enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
@@ -736,275 +727,6 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
         const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
         if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag, PRE ? &pre : nullptr);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Hot-column variant (heavy-tailed graphs: the synthetic Yelp2018 / Amazon-Book shapes).
-//
-// On a power-law graph a few hundred columns take a third of all gathers (top 192 of 69 716 rows: 30 % at the Yelp
-// shape, top 96 of 144 242: 24 % at the Amazon shape; Gowalla: 5 % -- the standard kernel stays there).  A gather that
-// hits L2 still costs its CU's vector-memory path ~28 cycles per wave-instruction, and that path is what bounds the fp32
-// layer.  So: PERSISTENT workgroups (HOT_WAVES waves, HOT_WGS_PER_XCD per XCD slice = two per CU) copy the H hottest rows
-// of X into LDS once per launch (H * D * 4 <= HOT_LDS_BYTES) and then walk the slice's work items -- chunks of long rows,
-// then packs of short rows -- wave by wave, item i to wave i mod (waves of the slice).  The plan keeps every row's hot
-// entries in a stream of their own, as (LDS slot, value): a pack / chunk is processed twice through the same staging
-// code, first its hot entries with the LDS table as the gather source (ds_read_b128, no vector-memory instruction), then
-// its cold entries exactly as k_spmm does.  A row is still one accumulator chain in a fixed order (hot entries in
-// column order, then cold entries in column order): bitwise reproducible, independent of the processing order, of the
-// XCD cut and of a row-sharded plan's subset (the hot set is a function of the whole matrix' column counts).
-// ---------------------------------------------------------------------------------
-#ifndef HOT_WAVES
-#define HOT_WAVES 12          /* waves per persistent workgroup */
-#endif
-#ifndef HOT_IPW
-#define HOT_IPW 2             /* work items per wave: a workgroup serves HOT_WAVES * HOT_IPW consecutive items of its slice and ends; the
-                                 hardware dispatcher balances the workgroups (a static deal of a slice's items to resident persistent
-                                 waves measured 40 % SLOWER than k_spmm: one 512-entry chunk more or less per wave decides the tail) */
-#endif
-#ifndef HOT_LDS_BYTES
-#define HOT_LDS_BYTES 49152   /* LDS of the hot table: H = HOT_LDS_BYTES / (d_max * 4) rows (d = 64: 192) */
-#endif
-#ifndef HOT_MIN_D
-#define HOT_MIN_D 64          /* d = 32 packs 8 rows per wave: the staging area of 12 waves leaves room for one workgroup per CU only */
-#endif
-#ifndef HOT_MAX_D
-#define HOT_MAX_D 128         /* d = 256: 48 rows of LDS table cover too little to pay (and hipcc 7.2 crashes in LICM on that instantiation) */
-#endif
-#ifndef HOT_MIN_COVER
-#define HOT_MIN_COVER 0.15    /* build / use the hot plan when the H hottest columns take at least this share of the gathers */
-#endif
-
-template <typename TI> struct HotRaw;
-template <> struct HotRaw<float> {
-    typedef f32x4 T; static constexpr int CPL = 4;
-    static __device__ __forceinline__ f32x4 cvt(const T &r) { return r; }
-};
-template <> struct HotRaw<bf16_t> {
-    typedef bf16x8 T; static constexpr int CPL = 8;
-    static __device__ __forceinline__ f32x8 cvt(const T &r) { return __builtin_convertvector(r, f32x8); }
-};
-
-// U entries of a lane group's own row from the LDS hot table (p: staged (slot, val) entries, zero-weight padded)
-template <int D, typename TI, int U, int GPR>
-__device__ __forceinline__ void hot_batch(const int2 *p, const char *hot, int l, typename Geo<D, TI, false>::Acc &acc) {
-    typedef HotRaw<TI> R;
-    int2 cv[U]; typename R::T xr[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) cv[u] = p[u * GPR];
-#pragma unroll
-    for (int u = 0; u < U; u++) xr[u] = *reinterpret_cast<const typename R::T *>(hot + cv[u].x * (int)(D * sizeof(TI)) + l * 16);
-#pragma unroll
-    for (int u = 0; u < U; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u]);
-}
-// the same for a staged tile shared by the wave's NPW lane groups (long rows)
-template <int D, typename TI>
-__device__ __forceinline__ void hot_tile(const int2 *stage, int cnt, const char *hot, int lane, typename Geo<D, TI, false>::Acc &acc) {
-    typedef Geo<D, TI, false> G;
-    typedef HotRaw<TI> R;
-    const int g = lane / G::LPR, l = lane % G::LPR;
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
-    for (int j = 0; j < cnt; j += 4 * G::NPW) {              // (past the end: the tile's zero-weight padding, slot 0)
-        int2 cv[4]; typename R::T xr[4];
-        const int2 *p = stage + j + g;
-#pragma unroll
-        for (int u = 0; u < 4; u++) cv[u] = p[u * G::NPW];
-#pragma unroll
-        for (int u = 0; u < 4; u++) xr[u] = *reinterpret_cast<const typename R::T *>(hot + cv[u].x * (int)(D * sizeof(TI)) + l * 16);
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc += __int_as_float(cv[u].y) * R::cvt(xr[u]);
-    }
-}
-
-// stage the entries of a pack (contiguous in `stream` from `base`, row r at [off[r], off[r+1])) into the wave's per-row
-// stage rows, followed by the zero-weight tail up to GPR * (maxcnt + 3); returns maxcnt = longest row share
-template <int RPK, int GPR, int ST>
-__device__ __forceinline__ int pack_stage(const int2 *cvr, const int *off, int lane, int2 *stage) {
-    const int tot = off[RPK];
-#pragma unroll
-    for (int it = 0; it < RPK; it++) {
-        if (it * 64 < tot) {
-            const int e = it * 64 + lane;
-            int r = 0, o_r = 0;
-#pragma unroll
-            for (int k = 1; k < RPK; k++) { const bool ge = e >= off[k]; r += ge ? 1 : 0; o_r = ge ? off[k] : o_r; }
-            if (e < tot) stage[r * ST + (e - o_r)] = cvr[it];
-        }
-    }
-    int maxcnt = 0;
-#pragma unroll
-    for (int r = 0; r < RPK; r++) maxcnt = max(maxcnt, (off[r + 1] - off[r] + GPR - 1) / GPR);
-    const int padto = GPR * (maxcnt + 3);
-#pragma unroll
-    for (int r = 0; r < RPK; r++)
-        for (int q = off[r + 1] - off[r] + lane; q < padto; q += 64) stage[r * ST + q] = make_int2(0, 0);
-    return maxcnt;
-}
-
-template <int D, typename TI, typename TO, int MODE, bool BIG>
-__global__ void __launch_bounds__(64 * HOT_WAVES, (2 * HOT_WAVES) / 4) k_spmm_hot(SpmmArgs a) {
-    static_assert((MODE & M_SPARSE) == 0, "the sparse-input layer gathers flagged gradient rows: no hot table");
-    typedef Geo<D, TI, false> G;
-    typedef typename G::Acc Acc;
-    constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
-    constexpr int GPR = RowGeo<D, TI, false>::GPR, RPK = RowGeo<D, TI, false>::RPK;
-    constexpr int ST = 76, U = SPMM_U;
-    constexpr int STAGE = (RPK * ST > TILE_ST ? RPK * ST : TILE_ST);
-    constexpr int ROWB = D * (int)sizeof(TI);
-    __shared__ __attribute__((aligned(16))) char hot_lds[HOT_LDS_BYTES];
-    __shared__ int2 stage_lds[HOT_WAVES][STAGE];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ---- the hot rows of X into LDS: 16 bytes per thread and step, rows in slot order
-    {
-        constexpr int LR = ROWB / 16;                 // 16-byte pieces per row
-        const int pieces = a.n_hot * LR;
-        for (int i = threadIdx.x; i < pieces; i += 64 * HOT_WAVES) {
-            const int h = i / LR, q = i % LR;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>((const char *)a.X + (int64_t)a.hot_cols[h] * ROWB + q * 16);
-            *reinterpret_cast<f32x4 *>(hot_lds + h * ROWB + q * 16) = v;
-        }
-    }
-    if ((MODE & M_ADAM) && a.clear && blockIdx.x == 0 && wid == HOT_WAVES - 1)
-        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane);
-    __syncthreads();
-    GatherSrc src; src.X = a.X; src.bm = a.bitmap; src.div = a.div;
-    const int x = blockIdx.x & (XCDS - 1), jwg = blockIdx.x >> 3;
-    const int ncb = (a.sp.cblk[x + 1] - a.sp.cblk[x]) * 4;                 // chunk slots of the slice (padded to fours)
-    const int npk = (a.sp.rows[x + 1] - a.sp.rows[x]) / RPK;              // packs of the slice
-    int2 *stage = stage_lds[wid];
-    const int g = lane / LPR, l = lane % LPR;
-    // (no `#pragma unroll 1` here: with it hipcc 7.2's LICM pass crashes on this loop; the body is never unrolled anyway)
-    const int item_end = min(ncb + npk, (jwg + 1) * HOT_WAVES * HOT_IPW);
-    for (int item = jwg * HOT_WAVES * HOT_IPW + wid; item < item_end; item += HOT_WAVES) {
-        if (item < ncb) {
-            // ---- one chunk of a long row: its hot entries from LDS, then its cold entries as k_spmm gathers them
-            const int c = a.sp.cblk[x] * 4 + item;
-            const int4 ch = a.chunks_cold[c];
-            const int o = ch.x;
-            if (o < 0) continue;
-            const int2 hr = a.chunks_hot[c];
-            const int64_t row = a.lp.long_row[o];
-            const int nch = a.lp.long_nch[o];
-            const bool rflag = (MODE & M_ADDG) ? bit_set(a.bitmap, (int)row) : false;
-            Acc acc = zerov<C>();
-            tile_pad_init(stage, lane);
-            {
-                int2 cv = make_int2(0, 0);
-                if (hr.x + lane < hr.y) cv = a.pk_hot[hr.x + lane];
-                for (int base = hr.x; base < hr.y; base += 64) {
-                    const int n = min(64, hr.y - base);
-                    stage[lane] = lane < n ? cv : make_int2(0, 0);
-                    __builtin_amdgcn_wave_barrier();
-                    if (base + 64 + lane < hr.y) cv = a.pk_hot[base + 64 + lane];
-                    hot_tile<D, TI>(stage, n, hot_lds, lane, acc);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            {
-                int2 cv = make_int2(0, 0);
-                if (ch.y + lane < ch.z) cv = a.pk_cold[ch.y + lane];
-                for (int base = ch.y; base < ch.z; base += 64) {
-                    const int n = min(64, ch.z - base);
-                    const int cnt = tile_stage<false>(cv.x, __int_as_float(cv.y), n, src, lane, stage);
-                    __builtin_amdgcn_wave_barrier();
-                    if (base + 64 + lane < ch.z) cv = a.pk_cold[base + 64 + lane];
-                    tile_gather<D, TI, false, BIG>(stage, cnt, src, lane, acc);
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            acc = reduce_groups<LPR>(acc);
-            if (nch == 1) {
-                if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc, rflag);
-                continue;
-            }
-            // hand-off of a split row: exactly k_spmm's protocol (write-through partial, drain, ticket, last arriver sums)
-            typedef __attribute__((address_space(1))) unsigned long long gu64;
-            if (lane < LPR) {
-                union { Acc v; unsigned long long q[C / 2]; } pk; pk.v = acc;
-                gu64 *dst = (gu64 *)(a.lp.partials + (int64_t)c * D + lane * C);
-#pragma unroll
-                for (int i = 0; i < C / 2; i++) __hip_atomic_store(dst + i, pk.q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(a.lp.counters + o, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ticket = __builtin_amdgcn_readfirstlane(ticket);
-            if (ticket != nch - 1) continue;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(a.lp.counters + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-            if (lane < LPR) {
-                const int first = c - ch.w;
-                Acc tot = zerov<C>();
-                for (int k = 0; k < nch; k++) {
-                    union { Acc v; unsigned long long q[C / 2]; } pk;
-                    gu64 *sp_ = (gu64 *)(a.lp.partials + (int64_t)(first + k) * D + lane * C);
-#pragma unroll
-                    for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(sp_ + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (k == 0) tot = pk.v; else tot += pk.v;
-                }
-                spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot, rflag);
-            }
-            continue;
-        }
-        // ---- a pack of RPK short rows, one row per lane group (GPR groups per row)
-        const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)(item - ncb) * RPK;
-        int my_row = -1, my_cs = 0, my_cn = 0, my_hn = 0, my_hs = 0;
-        if (lane < RPK) {
-            const int4 ri = a.rowinfo_hot[pos0 + lane];
-            my_row = ri.x; my_cs = ri.y; my_cn = ri.z & 255; my_hn = ri.z >> 8; my_hs = ri.w;
-        }
-        uint32_t my_fw = 0u;
-        if ((MODE & M_ADDG) && my_row >= 0) my_fw = a.bitmap[my_row >> 5];
-        if (__builtin_amdgcn_readlane(my_row, 0) < 0) continue;       // padding at the end of a slice (other waves' items follow: no break)
-        int offc[RPK + 1], offh[RPK + 1];
-        offc[0] = 0; offh[0] = 0;
-#pragma unroll
-        for (int r = 0; r < RPK; r++) {
-            offc[r + 1] = offc[r] + __builtin_amdgcn_readlane(my_cn, r);
-            offh[r + 1] = offh[r] + __builtin_amdgcn_readlane(my_hn, r);
-        }
-        const int64_t cbase = __builtin_amdgcn_readlane(my_cs, 0), hbase = __builtin_amdgcn_readlane(my_hs, 0);
-        int2 cvc[RPK], cvh[RPK];
-#pragma unroll
-        for (int it = 0; it < RPK; it++) {
-            cvc[it] = make_int2(0, 0); cvh[it] = make_int2(0, 0);
-            if (it * 64 < offc[RPK]) { const int e = it * 64 + lane; if (e < offc[RPK]) cvc[it] = a.pk_cold[cbase + e]; }
-            if (it * 64 < offh[RPK]) { const int e = it * 64 + lane; if (e < offh[RPK]) cvh[it] = a.pk_hot[hbase + e]; }
-        }
-        const int myr = g / GPR, sub = g % GPR;
-        const int2 *mystage = stage + myr * ST + sub;
-        Acc acc = zerov<C>();
-        // hot entries first: the LDS table is the gather source
-        if (offh[RPK] > 0) {
-            const int maxh = __builtin_amdgcn_readfirstlane(pack_stage<RPK, GPR, ST>(cvh, offh, lane, stage));
-            __builtin_amdgcn_wave_barrier();
-            int u0 = 0;
-            for (; maxh - u0 > 2; u0 += 4) hot_batch<D, TI, 4, GPR>(mystage + GPR * u0, hot_lds, l, acc);
-            for (; maxh - u0 > 1; u0 += 2) hot_batch<D, TI, 2, GPR>(mystage + GPR * u0, hot_lds, l, acc);
-            if (maxh - u0 > 0) hot_batch<D, TI, 1, GPR>(mystage + GPR * u0, hot_lds, l, acc);
-            __builtin_amdgcn_wave_barrier();
-        }
-        const int maxcnt = __builtin_amdgcn_readfirstlane(pack_stage<RPK, GPR, ST>(cvc, offc, lane, stage));
-        __builtin_amdgcn_wave_barrier();
-        const int mrow = __shfl(my_row, myr);
-        constexpr bool PRE = false;      // (Adam's operand prefetch of k_spmm costs 14 registers: two workgroups per CU need <= 80)
-        AdamPre<C> pre; pre.have = false;
-        int u0 = 0;
-#define PACK_BATCH(UU) pack_batch<D, TI, false, UU, GPR, PRE, BIG>(mystage + GPR * u0, src, l, acc, &a, -1, false, &pre)
-        if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) PACK_BATCH((U >= 8 ? 8 : U));
-        if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) PACK_BATCH((U >= 4 ? 4 : U));
-        for (; maxcnt - u0 > 1; u0 += 2) PACK_BATCH(2);
-        if (maxcnt - u0 > 0) PACK_BATCH(1);
-#undef PACK_BATCH
-        if (GPR > 1) {
-#pragma unroll
-            for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);
-        }
-        const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
-        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag, nullptr);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1393,21 +1115,6 @@ static void launch_spmm_t(const SpmmArgs &a, hipStream_t st) {
     }
     if (a.remap) grid = widest * XCDS;
     if (grid == 0) return;
-    if constexpr (!(MODE & M_SPARSE) && D >= HOT_MIN_D && D <= HOT_MAX_D) {
-        if (a.n_hot > 0) {       // heavy-tailed graph: workgroups with the hot rows of X in LDS
-            constexpr int RPKH = RowGeo<D, TI, false>::RPK;
-            unsigned wmax = 0;
-            for (int x = 0; x < XCDS; x++) {
-                const unsigned items = (unsigned)((a.sp.cblk[x + 1] - a.sp.cblk[x]) * 4 + (a.sp.rows[x + 1] - a.sp.rows[x]) / RPKH);
-                wmax = std::max(wmax, (items + HOT_WAVES * HOT_IPW - 1) / (HOT_WAVES * HOT_IPW));
-            }
-            if (wmax == 0) return;
-            const dim3 hg(XCDS * wmax), hb(64 * HOT_WAVES);
-            if (big_table(a.n_rows, D)) hipLaunchKernelGGL((k_spmm_hot<D, TI, TO, MODE, true>), hg, hb, 0, st, a);
-            else hipLaunchKernelGGL((k_spmm_hot<D, TI, TO, MODE, false>), hg, hb, 0, st, a);
-            return;
-        }
-    }
     if (big_table(a.n_rows, D)) hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE, true>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
     else hipLaunchKernelGGL((k_spmm<D, TI, TO, MODE, false>), dim3(grid), dim3(64 * SPMM_WPB), 0, st, a);
 }
@@ -1464,9 +1171,6 @@ struct lgcn_graph {
     int64_t n_rows, nnz;
     int32_t d_max;
     LongPlan lp; SlicePlan sp;
-    // hot-column plan (heavy-tailed graphs; see k_spmm_hot): n_hot = 0 when the graph has none
-    const int2 *pk_cold; const int2 *pk_hot; const int4 *rowinfo_hot; const int4 *chunks_cold; const int2 *chunks_hot;
-    const int32_t *hot_cols; int32_t n_hot; double hot_cover; bool use_hot;
     void *owned;          // one device allocation holding plan arrays, partials and counters
     // The long-row scratch (partials, tickets) is shared by every launch on this graph: launches
     // are ordered.  A launch on another stream than the previous one first waits for it.
@@ -1505,71 +1209,19 @@ __global__ void __launch_bounds__(256) k_pack_stream(const int4 *items, int64_t 
     }
 }
 
-// ---- hot-column plan helpers
-// how often every column is gathered by one pass over the whole matrix
-__global__ void __launch_bounds__(256) k_col_count(const int32_t *indices, int64_t nnz, int32_t *cnt) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) atomicAdd(cnt + indices[i], 1);
-}
-// hot entries per row (hot_slot[col] >= 0), one wave per row
-__global__ void __launch_bounds__(256) k_row_hot_count(const int32_t *indptr, const int32_t *indices, const int32_t *hot_slot,
-                                                       int64_t n_rows, int32_t *out) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
-        int c = 0;
-        for (int e = indptr[r] + lane; e < indptr[r + 1]; e += 64) c += hot_slot[indices[e]] >= 0 ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) out[r] = c;
-    }
-}
-// split the planned rows' CSR segments into the cold stream (col, val) and the hot stream (LDS slot, val), column order
-// kept inside each: items = (first CSR entry, first cold position, first hot position, count), one wave per item
-__global__ void __launch_bounds__(256) k_pack_hot(const int4 *items, int64_t n_items, const int32_t *indices, const float *vals,
-                                                  const int32_t *hot_slot, int2 *pkc, int2 *pkh) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t i = wave; i < n_items; i += nwaves) {
-        const int4 it = items[i];
-        int nc = 0, nh = 0;
-        for (int e0 = 0; e0 < it.w; e0 += 64) {
-            const int e = e0 + lane;
-            const bool in = e < it.w;
-            const int col = in ? indices[(int64_t)it.x + e] : 0;
-            const float v = in ? vals[(int64_t)it.x + e] : 0.f;
-            const int slot = in ? hot_slot[col] : -1;
-            const unsigned long long mh = __ballot(in && slot >= 0), mc = __ballot(in && slot < 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (in && slot >= 0) pkh[(int64_t)it.z + nh + __popcll(mh & below)] = make_int2(slot, __float_as_int(v));
-            if (in && slot < 0) pkc[(int64_t)it.y + nc + __popcll(mc & below)] = make_int2(col, __float_as_int(v));
-            nh += __popcll(mh); nc += __popcll(mc);
-        }
-    }
-}
-
 static int graph_create_impl(const int32_t *indptr, const int32_t *indices, const float *vals,
                              int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, bool want_hot, lgcn_graph **out);
+                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, lgcn_graph **out);
 extern "C" int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float *vals,
                                  int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
                                  int64_t n_order, const int64_t *xcd_start, lgcn_graph **out) {
-    return graph_create_impl(indptr, indices, vals, n_rows, nnz, d_max, row_order, n_order, xcd_start, LONG_CH, true, out);
-}
-extern "C" int lgcn_graph_set_hot(lgcn_graph *g, int on) {
-    if (!g) { lgcn_set_error("lgcn_graph_set_hot: null graph"); return 3; }
-    g->use_hot = on != 0;
-    return 0;
-}
-extern "C" int lgcn_graph_hot_info(const lgcn_graph *g, int32_t *n_hot, double *cover) {
-    if (!g) { lgcn_set_error("lgcn_graph_hot_info: null graph"); return 3; }
-    if (n_hot) *n_hot = g->n_hot;
-    if (cover) *cover = g->hot_cover;
-    return 0;
+    return graph_create_impl(indptr, indices, vals, n_rows, nnz, d_max, row_order, n_order, xcd_start, LONG_CH, out);
 }
 // long_ch: non-zeros per chunk of a split row (LONG_CH for the propagation plans; the hub plan of k_triplet, whose rows
 // have 10^4 .. 10^6 non-zeros, takes longer chunks so that a row's last arriver has hundreds, not thousands, of partials to add)
 static int graph_create_impl(const int32_t *indptr, const int32_t *indices, const float *vals,
                              int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
-                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, bool want_hot, lgcn_graph **out) {
+                             int64_t n_order, const int64_t *xcd_start, int32_t long_ch, lgcn_graph **out) {
     if (!indptr || !indices || !vals || !out || n_rows <= 0 || nnz < 0 || nnz > 0x7fffffffLL ||
         n_rows >= 0x7fffffffLL) { lgcn_set_error("lgcn_graph_create: invalid argument"); return 3; }
     if (d_max != 32 && d_max != 64 && d_max != 128 && d_max != 256) { lgcn_set_error("lgcn_graph_create: d_max must be 32, 64, 128 or 256"); return 3; }
@@ -1629,51 +1281,9 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
         while (x <= XCDS) xs[x++] = n_order;
         xs[XCDS] = n_order;
     }
-    // ---- hot columns: on a heavy-tailed graph the H most gathered columns (H rows of X fit HOT_LDS_BYTES of LDS) take a
-    //      large share of all gathers; k_spmm_hot serves them from LDS.  The hot set is a function of the WHOLE matrix
-    //      (never of row_order / a row subset), ties broken by column id: every plan of one matrix has the same set.
-    std::vector<int32_t> hot_cols_h, rowhot;
-    int32_t n_hot = 0; double hot_cover = 0.0;
-    int32_t *d_hot_slot = nullptr;
-    struct HotGuard { int32_t *&p; ~HotGuard() { if (p) (void)hipFree(p); } } hot_guard{d_hot_slot};
-    if (want_hot && nnz > 0 && d_max >= HOT_MIN_D && d_max <= HOT_MAX_D) {
-        const int32_t H = (int32_t)std::min<int64_t>(HOT_LDS_BYTES / (d_max * 4), n_rows);
-        std::vector<int32_t> cnt((size_t)n_rows);
-        HIP_OK(hipMalloc((void **)&d_hot_slot, sizeof(int32_t) * (size_t)n_rows * 2));
-        HIP_OK(hipMemset(d_hot_slot, 0, sizeof(int32_t) * (size_t)n_rows));
-        {
-            const int64_t blocks = (nnz + 255) / 256;
-            hipLaunchKernelGGL(k_col_count, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, 0, indices, nnz, d_hot_slot);
-        }
-        HIP_OK(hipMemcpy(cnt.data(), d_hot_slot, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
-        std::vector<int32_t> ids((size_t)n_rows);
-        for (int64_t i = 0; i < n_rows; i++) ids[(size_t)i] = (int32_t)i;
-        auto hotter = [&](int32_t p, int32_t q) { return cnt[(size_t)p] != cnt[(size_t)q] ? cnt[(size_t)p] > cnt[(size_t)q] : p < q; };
-        if (H >= 16) {
-            std::partial_sort(ids.begin(), ids.begin() + H, ids.end(), hotter);
-            int64_t top = 0;
-            for (int32_t h = 0; h < H; h++) top += cnt[(size_t)ids[(size_t)h]];
-            hot_cover = (double)top / (double)nnz;
-            if (hot_cover >= HOT_MIN_COVER) {
-                n_hot = H;
-                hot_cols_h.assign(ids.begin(), ids.begin() + H);
-                std::vector<int32_t> slot((size_t)n_rows, -1);
-                for (int32_t h = 0; h < H; h++) slot[(size_t)hot_cols_h[(size_t)h]] = h;
-                HIP_OK(hipMemcpy(d_hot_slot, slot.data(), sizeof(int32_t) * slot.size(), hipMemcpyHostToDevice));
-                const int64_t blocks = (n_rows + 3) / 4;
-                hipLaunchKernelGGL(k_row_hot_count, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, 0,
-                                   indptr, indices, d_hot_slot, n_rows, d_hot_slot + n_rows);
-                rowhot.resize((size_t)n_rows);
-                HIP_OK(hipMemcpy(rowhot.data(), d_hot_slot + n_rows, sizeof(int32_t) * rowhot.size(), hipMemcpyDeviceToHost));
-            }
-        }
-    }
-    const bool hot = n_hot > 0;
     // ---- per slice: chunks of its long rows (padded to whole workgroups), then its short rows; the
     //      planned rows' entries go into the packed stream in exactly that order
     std::vector<int32_t> long_row, long_nch, chunks, rowinfo, copyplan;
-    std::vector<int32_t> chunks_c, chunks_h, rowinfo_h, copyplan_h;       // the hot plan's view of the same chunk slots / short rows
-    int64_t n_pkc = 0, n_pkh = 0;
     SlicePlan sp{};
     rowinfo.reserve((size_t)n_order * 4 + 4 * SLICE_PAD * XCDS);
     copyplan.reserve((size_t)n_order * 4);
@@ -1695,22 +1305,10 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
                 const int32_t cp[4] = {s0, lb, deg, 0};
                 copyplan.insert(copyplan.end(), cp, cp + 4);
                 n_pk += deg;
-                if (hot) {          // the same chunks, each with its share of the row's cold and of its hot entries
-                    const int64_t hh = rowhot[(size_t)r], cc = deg - hh;
-                    for (int k = 0; k < nch; k++) {
-                        const int32_t ec[4] = {(int32_t)long_row.size(), (int32_t)(n_pkc + cc * k / nch), (int32_t)(n_pkc + cc * (k + 1) / nch), k};
-                        const int32_t eh[2] = {(int32_t)(n_pkh + hh * k / nch), (int32_t)(n_pkh + hh * (k + 1) / nch)};
-                        chunks_c.insert(chunks_c.end(), ec, ec + 4); chunks_h.insert(chunks_h.end(), eh, eh + 2);
-                    }
-                    const int32_t cph[4] = {s0, (int32_t)n_pkc, (int32_t)n_pkh, deg};
-                    copyplan_h.insert(copyplan_h.end(), cph, cph + 4);
-                    n_pkc += cc; n_pkh += hh;
-                }
                 long_row.push_back(r); long_nch.push_back(nch);
             } else {
                 const int32_t e[4] = {r, s0, deg, 0};
                 rowinfo.insert(rowinfo.end(), e, e + 4);
-                if (hot) { const int32_t eh[4] = {r, s0, deg, rowhot[(size_t)r]}; rowinfo_h.insert(rowinfo_h.end(), eh, eh + 4); }
             }
         }
         // rows of a pack run in lock step: sort every window of SHORT_WIN short rows by length (stable)
@@ -1729,29 +1327,6 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
             n_pk += rowinfo[i + 2];
         }
         const int32_t pad[4] = {-1, 0, 0, 0};
-        if (hot) {
-            // the hot plan's packs run their cold (gathered) part in lock step: sort the windows by COLD length
-            const size_t hb = slice_begin;            // rowinfo_h grows in step with rowinfo: same offsets
-            for (size_t w0 = hb; w0 < rowinfo_h.size(); w0 += 4 * SHORT_WIN) {
-                const size_t w1 = std::min(rowinfo_h.size(), w0 + 4 * (size_t)SHORT_WIN), n = (w1 - w0) / 4;
-                std::vector<std::array<int32_t, 4>> tmp(n);
-                for (size_t i = 0; i < n; i++) for (int k = 0; k < 4; k++) tmp[i][k] = rowinfo_h[w0 + 4 * i + k];
-                std::stable_sort(tmp.begin(), tmp.end(), [](const std::array<int32_t, 4> &p, const std::array<int32_t, 4> &q) {
-                    const int cp_ = p[2] - p[3], cq_ = q[2] - q[3];
-                    return cp_ != cq_ ? cp_ > cq_ : p[3] > q[3]; });
-                for (size_t i = 0; i < n; i++) for (int k = 0; k < 4; k++) rowinfo_h[w0 + 4 * i + k] = tmp[i][k];
-            }
-            for (size_t i = hb; i < rowinfo_h.size(); i += 4) {
-                const int32_t deg = rowinfo_h[i + 2], hh = rowinfo_h[i + 3];
-                const int32_t cph[4] = {rowinfo_h[i + 1], (int32_t)n_pkc, (int32_t)n_pkh, deg};
-                if (deg > 0) copyplan_h.insert(copyplan_h.end(), cph, cph + 4);
-                rowinfo_h[i + 1] = (int32_t)n_pkc; rowinfo_h[i + 2] = (deg - hh) | (hh << 8); rowinfo_h[i + 3] = (int32_t)n_pkh;
-                n_pkc += deg - hh; n_pkh += hh;
-            }
-            const int32_t pad2[2] = {0, 0};
-            while ((chunks_c.size() / 4) % 4) { chunks_c.insert(chunks_c.end(), pad, pad + 4); chunks_h.insert(chunks_h.end(), pad2, pad2 + 2); }
-            while ((rowinfo_h.size() / 4) % SLICE_PAD) rowinfo_h.insert(rowinfo_h.end(), pad, pad + 4);
-        }
         while ((chunks.size() / 4) % 4) chunks.insert(chunks.end(), pad, pad + 4);
         while ((rowinfo.size() / 4) % SLICE_PAD) rowinfo.insert(rowinfo.end(), pad, pad + 4);
     }
@@ -1761,8 +1336,6 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
     g->indptr = indptr; g->indices = indices; g->vals = vals; g->rowinfo = nullptr; g->pk = nullptr;
     g->n_rows = n_rows; g->nnz = nnz; g->d_max = d_max;
     g->owned = nullptr; g->lp = LongPlan{}; g->sp = sp;
-    g->pk_cold = nullptr; g->pk_hot = nullptr; g->rowinfo_hot = nullptr; g->chunks_cold = nullptr; g->chunks_hot = nullptr;
-    g->hot_cols = nullptr; g->n_hot = 0; g->hot_cover = hot_cover; g->use_hot = true;
     g->used = false; g->last_stream = nullptr; g->order_ev = nullptr;
     if (hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming) != hipSuccess) { delete g; lgcn_set_error("lgcn_graph_create: hipEventCreate failed"); return 10; }
     const size_t n_long = long_row.size(), n_slots = chunks.size() / 4, n_info = rowinfo.size() / 4;
@@ -1771,11 +1344,7 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
         const size_t o_info = 0, o_chk = up(o_info + 16 * n_info), o_row = up(o_chk + 16 * n_slots),
                      o_nch = up(o_row + 4 * n_long), o_cnt = up(o_nch + 4 * n_long),
                      o_par = up(o_cnt + 4 * n_long), o_pk = up(o_par + n_slots * (size_t)d_max * 4),
-                     // hot plan (empty when the graph has none)
-                     o_hinfo = up(o_pk + 8 * (size_t)n_pk), o_hchc = up(o_hinfo + 4 * rowinfo_h.size()),
-                     o_hchh = up(o_hchc + 4 * chunks_c.size()), o_hcols = up(o_hchh + 4 * chunks_h.size()),
-                     o_pkc = up(o_hcols + 4 * hot_cols_h.size()), o_pkh = up(o_pkc + 8 * (size_t)n_pkc),
-                     total = o_pkh + 8 * (size_t)n_pkh + 256;
+                     total = o_pk + 8 * (size_t)n_pk + 256;
         char *base = nullptr;
         if (hipMalloc((void **)&base, total) != hipSuccess) { (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: hipMalloc failed"); return 4; }
         g->owned = base;
@@ -1798,31 +1367,7 @@ static int graph_create_impl(const int32_t *indptr, const int32_t *indices, cons
             }
             if (items) (void)hipFree(items);
         }
-        if (e1 == hipSuccess && hot) {
-            if (rowinfo_h.size() != rowinfo.size() || chunks_c.size() != chunks.size() || n_pkc + n_pkh != n_pk) e1 = hipErrorUnknown;      // the two plans must name the same slots
-            if (e1 == hipSuccess && !rowinfo_h.empty()) e1 = hipMemcpy(base + o_hinfo, rowinfo_h.data(), 4 * rowinfo_h.size(), hipMemcpyHostToDevice);
-            if (e1 == hipSuccess && !chunks_c.empty()) e1 = hipMemcpy(base + o_hchc, chunks_c.data(), 4 * chunks_c.size(), hipMemcpyHostToDevice);
-            if (e1 == hipSuccess && !chunks_h.empty()) e1 = hipMemcpy(base + o_hchh, chunks_h.data(), 4 * chunks_h.size(), hipMemcpyHostToDevice);
-            if (e1 == hipSuccess) e1 = hipMemcpy(base + o_hcols, hot_cols_h.data(), 4 * hot_cols_h.size(), hipMemcpyHostToDevice);
-            if (e1 == hipSuccess && !copyplan_h.empty()) {
-                int4 *items = nullptr;
-                e1 = hipMalloc((void **)&items, copyplan_h.size() * 4);
-                if (e1 == hipSuccess) e1 = hipMemcpy(items, copyplan_h.data(), copyplan_h.size() * 4, hipMemcpyHostToDevice);
-                if (e1 == hipSuccess) {
-                    const int64_t n_items = (int64_t)(copyplan_h.size() / 4), blocks = (n_items + 3) / 4;
-                    hipLaunchKernelGGL(k_pack_hot, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, 0,
-                                       items, n_items, indices, vals, d_hot_slot, (int2 *)(base + o_pkc), (int2 *)(base + o_pkh));
-                    e1 = hipDeviceSynchronize();
-                }
-                if (items) (void)hipFree(items);
-            }
-        }
         if (e1 != hipSuccess) { (void)hipFree(base); (void)hipEventDestroy(g->order_ev); delete g; lgcn_set_error("lgcn_graph_create: plan upload failed"); return 10; }
-        if (hot) {
-            g->rowinfo_hot = (const int4 *)(base + o_hinfo); g->chunks_cold = (const int4 *)(base + o_hchc);
-            g->chunks_hot = (const int2 *)(base + o_hchh); g->hot_cols = (const int32_t *)(base + o_hcols);
-            g->pk_cold = (const int2 *)(base + o_pkc); g->pk_hot = (const int2 *)(base + o_pkh); g->n_hot = n_hot;
-        }
         g->rowinfo = (const int4 *)(base + o_info);
         g->pk = (const int2 *)(base + o_pk);
         if (n_long) {
@@ -1847,10 +1392,6 @@ extern "C" void lgcn_graph_destroy(lgcn_graph *g) {
 static SpmmArgs graph_spmm(const lgcn_graph *g) {
     SpmmArgs a{};
     a.pk = g->pk; a.rowinfo = g->rowinfo; a.lp = g->lp; a.sp = g->sp; a.n_rows = g->n_rows;
-    if (g->n_hot > 0 && g->use_hot) {
-        a.pk_cold = g->pk_cold; a.pk_hot = g->pk_hot; a.rowinfo_hot = g->rowinfo_hot; a.chunks_cold = g->chunks_cold;
-        a.chunks_hot = g->chunks_hot; a.hot_cols = g->hot_cols; a.n_hot = g->n_hot;
-    }
     return a;
 }
 
@@ -1984,7 +1525,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
                      hipMemcpy(dh, hubs.data(), sizeof(int32_t) * hubs.size(), hipMemcpyHostToDevice) == hipSuccess;
                 const int32_t hub_chunk = c.hub_chunk > 0 ? c.hub_chunk : TRIPLET_HUB_CHUNK;
                 if (ok) ok = graph_create_impl(c.graph->indptr, c.graph->indices, c.graph->vals, x->N, c.graph->nnz, c.d, dh,
-                                               (int64_t)hubs.size(), nullptr, hub_chunk, false, &x->hub_graph) == 0;
+                                               (int64_t)hubs.size(), nullptr, hub_chunk, &x->hub_graph) == 0;
                 if (dh) (void)hipFree(dh);
                 x->hub_nnz = thr; x->hub_rows = (int64_t)hubs.size();
             }

@@ -221,8 +221,6 @@ class LightGCN(nn.Module):
                                     d_max=self.latent_dim, row_order=order, xcd_start=xcd_start),
                 'ctx': None, 'max_batch': 0,
             }
-            if not int(self.config.get('hot_plan', 1)):
-                self._dev['graph'].set_hot(False)
         st = self._dev
         if row_subset is not None and st.get('graph_rs') is None:
             # row-sharded propagation: the training context works on a plan of the owned rows only
@@ -230,8 +228,6 @@ class LightGCN(nn.Module):
             g = st['graph']
             st['graph_rs'] = _lib.Graph(g.indptr, g.indices, g.vals, d_max=self.latent_dim,
                                         row_order=np.ascontiguousarray(row_subset, np.int32))
-            if not int(self.config.get('hot_plan', 1)):
-                st['graph_rs'].set_hot(False)
         if need_ctx:
             max_batch = int(max_batch or self.config.get('bpr_batch_size', 2048))
             # a context is bound to ONE plan: the owned rows (row-sharded epochs, which exchange the other rows) or all

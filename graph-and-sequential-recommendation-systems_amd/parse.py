@@ -71,9 +71,6 @@ def build_parser():
     p.add_argument('--dense_last', type=str, default='auto', choices=['auto', '0', '1'],
                    help='NEW: last forward layer on the batch rows only (0), densely (1), or whichever is cheaper for '
                         'this graph and batch size (auto)')
-    p.add_argument('--hot_plan', type=int, default=1,
-                   help='NEW: 1 = on heavy-tailed graphs the dense SpMM layers keep the most gathered rows in LDS (results '
-                        'change by fp32 summation order only); 0 = always the standard plan')
     p.add_argument('--hub_nnz', type=int, default=0,
                    help='NEW: graph rows with more non-zeros than this get their last-layer row from a whole-chip SpMM once per '
                         'step instead of from every triplet that names them (0 = library default 131072, < 0 = off)')

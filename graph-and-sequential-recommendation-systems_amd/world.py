@@ -103,7 +103,6 @@ def configure(argv=None):
     config['gpu_sampler'] = args.gpu_sampler
     config['dense_last'] = args.dense_last
     config['hub_nnz'] = args.hub_nnz
-    config['hot_plan'] = args.hot_plan
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

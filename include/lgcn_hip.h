@@ -121,14 +121,6 @@ int lgcn_graph_create(const int32_t *indptr, const int32_t *indices, const float
                       int64_t n_rows, int64_t nnz, int32_t d_max, const int32_t *row_order,
                       int64_t n_order, const int64_t *xcd_start, lgcn_graph **out);
 void lgcn_graph_destroy(lgcn_graph *g);
-/* Hot-column plan.  On a heavy-tailed graph (the H most gathered columns, H rows of X = 48 KiB of LDS, take >= 15 % of
- * all gathers) lgcn_graph_create also builds a plan whose dense SpMM launches keep those H rows of X in LDS (persistent
- * workgroups) and gather only the rest.  lgcn_graph_hot_info reports H (0: none built) and the share of the gathers
- * it covers; lgcn_graph_set_hot(g, 0) makes later launches on g use the standard plan (1, the default: the hot plan
- * where one exists).  Results differ between the two plans by fp32 summation order only (a row's hot entries are
- * summed before its other entries); either is bitwise reproducible and independent of row_order / xcd_start. */
-int lgcn_graph_set_hot(lgcn_graph *g, int on);
-int lgcn_graph_hot_info(const lgcn_graph *g, int32_t *n_hot, double *cover);
 
 /* Y = A_hat X  -- replaces torch.sparse.mm(g, x)                model.py:217
  * (and its autograd backward A^T g: A_hat is symmetric).  X,Y: [n_rows,d]

@@ -781,61 +781,6 @@ def test_spmm_hub_rows_forty_chunks(pkg, oracle, d, bf16):
     g.close()
 
 
-@pytest.mark.parametrize("d,bf16", [(64, False), (64, True), (128, False), (128, True)])
-def test_hot_column_plan_vs_oracle_and_standard_plan(pkg, oracle, d, bf16):
-    """k_spmm_hot (heavy-tailed graphs: persistent workgroups keep the H most gathered rows of X in LDS; a row's hot entries
-    are summed before its other entries) on a power-law graph whose hubs take most gathers: the graph builds a hot plan,
-    the result matches the oracle within the computed summation bound, a second launch and other row orders / XCD cuts /
-    a row-subset plan give the same bits, and the standard plan (lgcn_graph_set_hot(0)) agrees within the same bound.
-    Rows of every kind: empty, short with 0 / some / only hot entries, 65..512 (one chunk), split rows."""
-    rng = np.random.Generator(np.random.PCG64(900 + d))
-    n = 6000
-    pop = 1.0 / np.arange(1, n + 1) ** 1.1
-    pop = pop[rng.permutation(n)] / pop.sum()
-    lens = np.minimum(np.maximum(0, (rng.zipf(1.7, n) * 3).astype(np.int64) - 2), 3000)
-    lens[:8] = [0, 1, 64, 65, 512, 513, 1500, 2999]
-    rows = [np.sort(rng.choice(n, size=int(k), replace=False, p=pop)) if k else np.zeros(0, np.int64) for k in lens]
-    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
-    indices = np.concatenate(rows).astype(np.int32)
-    vals = rng.uniform(0.01, 0.4, len(indices)).astype(np.float32)
-    X = rng.normal(0, 0.1, (n, d)).astype(np.float32)
-    Xd = _dev(X).to(torch.bfloat16) if bf16 else _dev(X)
-    Xh = Xd.float().cpu().numpy()
-    ref = oracle.spmm(indptr, indices, vals, Xh)
-    bound = spmm_sum_bound(indptr, vals, indices, Xh)
-    g = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d)
-    n_hot, cover = g.hot_info()
-    assert n_hot == 49152 // (4 * d) and cover > 0.15, (n_hot, cover)
-    got = g.spmm(Xd, 0).cpu().numpy()
-    assert_rows_close(got, ref, bound, "hot plan vs oracle")
-    assert np.array_equal(got[lens == 0], np.zeros_like(got[lens == 0]))
-    assert np.array_equal(g.spmm(Xd, 0).cpu().numpy().view(np.uint32), got.view(np.uint32))       # tickets reset, same bits
-    g.set_hot(False)
-    std = g.spmm(Xd, 0).cpu().numpy()
-    assert_rows_close(std, ref, bound, "standard plan vs oracle")
-    assert not np.array_equal(std.view(np.uint32), got.view(np.uint32))                             # (it really was another kernel)
-    g.set_hot(True)
-    assert np.array_equal(g.spmm(Xd, 0).cpu().numpy().view(np.uint32), got.view(np.uint32))
-    g.close()
-    cut = np.array([0, 100, 100, 900, 2000, 2001, 4000, 5999, 6000], np.int64)
-    for order, xs in ((rng.permutation(n).astype(np.int32), None), (rng.permutation(n).astype(np.int32), cut)):
-        g2 = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=order, xcd_start=xs)
-        assert g2.hot_info()[0] == n_hot
-        assert np.array_equal(g2.spmm(Xd, 0).cpu().numpy().view(np.uint32), got.view(np.uint32))    # order / cut change no bit
-        g2.close()
-    sub = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.int32)                          # a rank's share of a row-sharded job
-    g3 = pkg._lib.Graph(_dev(indptr), _dev(indices), _dev(vals), d_max=d, row_order=sub)
-    assert g3.hot_info()[0] == n_hot                                                                  # hot set = function of the whole matrix
-    y = torch.full((n, d), 7.0, device=DEV)
-    pkg._lib.check(pkg._lib.load().lgcn_spmm_csr(g3.handle, pkg._lib.tp(Xd), 1 if bf16 else 0, pkg._lib.tp(y), 0, d,
-                                                 pkg._lib.current_stream()), "spmm subset")
-    y = y.cpu().numpy()
-    assert np.array_equal(y[sub].view(np.uint32), got[sub].view(np.uint32))
-    rest = np.setdiff1d(np.arange(n), sub)
-    assert np.all(y[rest] == 7.0)
-    g3.close()
-
-
 def _synthetic_model(pkg, name, act="fp32", row_order="xcd"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
