@@ -30,6 +30,10 @@ class TrainConfig(C.Structure):
         ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
         ("xcd_remap", C.c_int32), ("dense_last", C.c_int32),
         ("hub_nnz", C.c_int32), ("hub_chunk", C.c_int32),
+        ("i2i", _vp), ("i2i_t", _vp),
+        ("item_pop", _vp), ("gate_params", _vp), ("gate_adam_m", _vp), ("gate_adam_v", _vp), ("gate_grad", _vp),
+        ("pop_hidden", C.c_int32), ("gate_hidden", C.c_int32),
+        ("gate_entropy_coeff", C.c_float), ("pop_gate_temp", C.c_float),
     ]
 
 

@@ -343,11 +343,13 @@ struct SpmmArgs {
     // wave reduces the per-triplet loss terms, so no separate clean-up launch is needed
     int clear;
     const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
+    float ent_coeff;              // popularity gate: coefficient of the gates' entropy term in the loss (0: no gate)
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
+    const float *selfX;           // M_ADDSELF: Y[row] = selfX[row] + (A X)[row]  (item-item smoothing, model.py:228-229)
 };
 
-enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4 };
+enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4, M_ADDSELF = 8 };
 
 //   M_ADDG  : add Gs[row] where flagged (Horner term)
 //   M_ADAM  : apply torch.optim.Adam to P/M/V with grad = result, else store to Y
@@ -359,6 +361,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
                                               const AdamPre<C> *pre = nullptr) {
     typedef typename VecF<C>::T V;
     const int64_t off = row * D + l * C;
+    if (MODE & M_ADDSELF) acc = loadv<C>(a.selfX + off) + acc;
     if ((MODE & M_ADDG) && flagged) {      // (the row's bitmap word was fetched before the gathers -- a dependent load here measured +0.3-0.6 % on the step)
         V g = loadv<C>(a.G32 + off);          // = (float)(G64 * 2^-50) / (K+1), converted once by k_g32
         acc = g + acc;
@@ -391,9 +394,11 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
 // deterministic reduction of the per-triplet loss / reg terms by ONE wave (fixed strided
 // partials, then an xor-shuffle tree): loss_out = {bpr + decay*reg, bpr, reg}   (model.py:168-173)
 __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float *gathered, int B, int shard,
-                                                 int D, float decay, float *loss_out, int lane) {
+                                                 int D, float decay, float *loss_out, int lane, float ent_coeff = 0.f) {
     // Every lane adds its terms b = lane, lane + 64, ... in that order (the order is part of the result).
-    float fl = 0.f, fr = 0.f;
+    float fl = 0.f, fr = 0.f, fe = 0.f;
+    if (ent_coeff != 0.f)          // popularity gate: entropy of the 2B gates, one sum per triplet at terms[2B + b] (model.py:176-181)
+        for (int b = lane; b < B; b += 64) fe += terms[2 * B + b];
     if (!gathered) {
         // one GPU: the plain loop (deeper explicit batches made the launch it rides in slower: 3214-3278 steps/s at
         // B = 8192 for 32 ... 4 loads in flight, 3296 for this form)
@@ -425,9 +430,9 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { fl += __shfl_xor(fl, off); fr += __shfl_xor(fr, off); }
+    for (int off = 32; off > 0; off >>= 1) { fl += __shfl_xor(fl, off); fr += __shfl_xor(fr, off); fe += __shfl_xor(fe, off); }
     if (lane == 0) {
-        const float bpr = -(fl / (float)B);
+        const float bpr = -(fl / (float)B) - ent_coeff * (fe / (float)(2 * B));       // loss - coeff * entropy.mean()
         const float reg = (0.5f * fr) / (float)B;
         loss_out[0] = bpr + decay * reg; loss_out[1] = bpr; loss_out[2] = reg;
     }
@@ -545,7 +550,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
     //  sat on the tail and cost +25 us)
     if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == SPMM_WPB - 1)
-        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane);
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane, a.ent_coeff);
     int x, j;
     if (a.remap) { x = blockIdx.x & (XCDS - 1); j = blockIdx.x >> 3; }
     else {        // slices as contiguous block ranges (placement-independent either way: speed only)
@@ -788,6 +793,7 @@ struct BprArgs {
     long long *G64;       // if non-null: atomics
     uint32_t *bitmap;
     uint32_t *stale_bitmap; int64_t bitmap_words;   // last step's bitmap: zeroed here (plain stores)
+    uint32_t *item_bitmap;  // item-item smoothing: bit i = item i is named by the batch (or NULL)
     float *contrib;       // exchange block [3*shard*D | shard | shard] (data parallel)
     int32_t exchange;     // write the gradient rows and loss terms to `contrib` (instead of / besides the atomics)
     const float *Xhub; int32_t hub_nnz;     // rows with more than hub_nnz non-zeros: X_K[row] is read from Xhub (0: none)
@@ -848,7 +854,10 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
                           (unsigned long long)__double2ll_rn((double)g * FIXED_SCALE));
             if (a.exchange) a.contrib[((int64_t)c * a.shard + b) * D + j * LPT + l] = tbad ? 0.f : g;
         }
-        if (a.G64 && !tbad && l == 0) atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
+        if (a.G64 && !tbad && l == 0) {
+            atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
+            if (a.item_bitmap && c > 0) { const int64_t it = rows[c] - a.n_users; atomicOr(a.item_bitmap + (it >> 5), 1u << (it & 31)); }
+        }
     }
 }
 
@@ -1006,6 +1015,260 @@ __global__ void __launch_bounds__(256) k_triplet_dense(BprArgs a) {
     triplet_loss_regs<D>(a, b, l, e[0], e[1], e[2]);
 }
 
+// ---------------------------------------------------------------------------------
+// The fork's optional branches in the fused step.
+//
+// Popularity gate (model.py:66-96,139-157,176-181).  For an item i with propagated row e_i and popularity scalar s_i:
+//     a      = relu(W1 s_i + b1)                      pop_mlp[0]: Linear(1, Hp)
+//     pv     = W2 a + b2                               pop_mlp[2]: Linear(Hp, d)
+//     h      = relu(V1 [e_i ; pv] + c1)                gate_mlp[0]: Linear(2d, Hg)
+//     g      = sigmoid((V2 h + c2) / T)                gate_mlp[2]: Linear(Hg, 1)
+//     f_i    = g e_i + (1 - g) pv                      the row bpr_loss scores with
+//     loss   = bpr(u, f_p, f_n) - coeff * mean over the 2B gates of H(clamp(g, 1e-6, 1 - 1e-6))
+// bpr_loss reads f only on the 2B item slots of the batch, so the gate and its backward run on those slots: one wave per
+// triplet (lane = column for the row work, lane = hidden unit for the two MLPs), the MLP weights in LDS (V1 and W2 row
+// padded by one float: conflict-free both for "lane = unit walks a row" and "lane = column walks a column"), the
+// gradient rows w.r.t. e_u, e_p, e_n scattered with the same fixed-point atomics as k_triplet, and the parameter
+// gradients summed in two deterministic stages: per workgroup over its slots (phase 2 below, fixed slot order),
+// then over the workgroups in index order inside k_gate_adam, which also applies torch.optim.Adam to the MLP parameters.
+// ---------------------------------------------------------------------------------
+#define GATE_TPB 8            /* triplets per workgroup (two per wave) */
+#define GATE_S (2 * GATE_TPB) /* item slots per workgroup */
+#define GATE_HMAX 64          /* pop_hidden, gate_hidden <= 64 (lane = hidden unit) */
+struct GateArgs {
+    const float *E;               // [N,d] final propagated table (layer mean, item-item smoothing applied)
+    const float *item_pop;        // [m_items]
+    const float *params;          // flat: W1[Hp] b1[Hp] W2[d*Hp] b2[d] V1[Hg*2d] c1[Hg] V2[Hg] c2[1]  (torch.nn.Linear layouts)
+    float *partials;              // [grid, P] per-workgroup parameter-gradient sums
+    int32_t Hp, Hg, P;
+    float inv_temp, ent_scale;    // 1 / pop_gate_temp ; gate_entropy_coeff / (2 B)
+    int32_t n_users; int64_t N;
+    const int32_t *users; const int32_t *pos; const int32_t *neg;
+    int32_t B; float inv_B, lam;
+    long long *G64; uint32_t *bitmap; uint32_t *item_bitmap;      // item_bitmap: bit i = item i named by the batch (or NULL)
+    uint32_t *stale_bitmap; int64_t bitmap_words;
+    float *terms; int32_t terms_stride;
+    int32_t *err;
+};
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
+    constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT, D2 = 2 * D, V1S = D2 + 1;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int Hp = a.Hp, Hg = a.Hg, W2S = Hp + 1;
+    // LDS carve-up
+    float *V1p = gsm;                                  // [Hg][2d + 1]
+    float *W2p = V1p + GATE_HMAX * V1S;                // [d][Hp + 1]
+    float *W1 = W2p + D * (GATE_HMAX + 1);             // [Hp]
+    float *b1 = W1 + GATE_HMAX, *b2 = b1 + GATE_HMAX;  // [Hp], [d]
+    float *c1 = b2 + D, *V2 = c1 + GATE_HMAX;          // [Hg], [Hg]
+    float *IN = V2 + GATE_HMAX;                        // [S][2d]  gate input [e ; pv]
+    float *DH = IN + GATE_S * D2;                      // [S][Hmax] d loss / d (pre-activation of the gate's hidden layer)
+    float *HR = DH + GATE_S * GATE_HMAX;               // [S][Hmax] relu(h)
+    float *DPV = HR + GATE_S * GATE_HMAX;              // [S][d]   d loss / d pv
+    float *AA = DPV + GATE_S * D;                      // [S][Hmax] relu(a)
+    float *DA = AA + GATE_S * GATE_HMAX;               // [S][Hmax] d loss / d (pre-activation of the pop hidden layer)
+    float *SC = DA + GATE_S * GATE_HMAX;               // [S] popularity scalar
+    float *DLOG = SC + GATE_S;                         // [S] d loss / d logit
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.bitmap_words; i += (int64_t)gridDim.x * 256) a.stale_bitmap[i] = 0u;
+    const int oW2 = 2 * Hp, ob2 = oW2 + D * Hp, oV1 = ob2 + D, oc1 = oV1 + Hg * D2, oV2 = oc1 + Hg, oc2 = oV2 + Hg;
+    for (int i = tid; i < Hg * D2; i += 256) V1p[(i / D2) * V1S + i % D2] = a.params[oV1 + i];
+    for (int i = tid; i < D * Hp; i += 256) W2p[(i / Hp) * W2S + i % Hp] = a.params[oW2 + i];
+    if (tid < Hp) { W1[tid] = a.params[tid]; b1[tid] = a.params[Hp + tid]; }
+    for (int i = tid; i < D; i += 256) b2[i] = a.params[ob2 + i];
+    if (tid < Hg) { c1[tid] = a.params[oc1 + tid]; V2[tid] = a.params[oV2 + tid]; }
+    const float c2 = a.params[oc2];
+    // records of slots that end up unused (batch tail, bad ids) must read as zero in phase 2
+    for (int i = tid; i < GATE_S * GATE_HMAX; i += 256) { DH[i] = 0.f; HR[i] = 0.f; AA[i] = 0.f; DA[i] = 0.f; }
+    for (int i = tid; i < GATE_S * D; i += 256) DPV[i] = 0.f;
+    for (int i = tid; i < GATE_S * D2; i += 256) IN[i] = 0.f;
+    if (tid < GATE_S) { SC[tid] = 0.f; DLOG[tid] = 0.f; }
+    __syncthreads();
+    // ---- phase 1: one wave per triplet
+    for (int tt = w; tt < GATE_TPB; tt += 4) {
+        const int b = blockIdx.x * GATE_TPB + tt;
+        if (b >= a.B) break;
+        const int iu = a.users[b], ip = a.pos[b], in_ = a.neg[b];
+        const bool bad = iu < 0 || iu >= a.n_users || ip < 0 || (int64_t)ip + a.n_users >= a.N || in_ < 0 || (int64_t)in_ + a.n_users >= a.N;
+        if (bad) {
+            if (lane == 0) { atomicExch(a.err, 1); a.terms[b] = 0.f; a.terms[a.terms_stride + b] = 0.f; a.terms[2 * a.terms_stride + b] = 0.f; }
+            continue;
+        }
+        const bool col = lane < LPT;
+        float u[CPT], e[2][CPT], pv[2][CPT], f[2][CPT], g[2], ent[2];
+        const int item[2] = {ip, in_};
+#pragma unroll
+        for (int j = 0; j < CPT; j++) u[j] = col ? a.E[(int64_t)iu * D + j * LPT + lane] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int sidx = 2 * tt + q;
+            const int64_t row = (int64_t)item[q] + a.n_users;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) e[q][j] = col ? a.E[row * D + j * LPT + lane] : 0.f;
+            const float sc = a.item_pop[item[q]];
+            if (lane < Hp) AA[sidx * GATE_HMAX + lane] = fmaxf(W1[lane] * sc + b1[lane], 0.f);
+            if (lane == 0) SC[sidx] = sc;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int c = j * LPT + lane;
+                float acc = 0.f;
+                if (col) { acc = b2[c]; for (int k = 0; k < Hp; k++) acc += W2p[c * W2S + k] * AA[sidx * GATE_HMAX + k]; }
+                pv[q][j] = acc;
+                if (col) { IN[sidx * D2 + c] = e[q][j]; IN[sidx * D2 + D + c] = acc; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float hr = 0.f;
+            if (lane < Hg) {
+                float h = c1[lane];
+                for (int c = 0; c < D2; c++) h += V1p[lane * V1S + c] * IN[sidx * D2 + c];
+                hr = fmaxf(h, 0.f);
+                HR[sidx * GATE_HMAX + lane] = hr;
+            }
+            const float logit = (wave_sum(lane < Hg ? V2[lane] * hr : 0.f) + c2) * a.inv_temp;
+            g[q] = 1.f / (1.f + expf(-logit));                                 // torch.sigmoid
+            const float gc = fminf(fmaxf(g[q], 1e-6f), 1.f - 1e-6f);           // torch.clamp(gates, 1e-6, 1 - 1e-6)
+            ent[q] = -(gc * logf(gc) + (1.f - gc) * logf(1.f - gc));
+#pragma unroll
+            for (int j = 0; j < CPT; j++) f[q][j] = g[q] * e[q][j] + (1.f - g[q]) * pv[q][j];
+        }
+        // loss terms (model.py:168-173 on the fused rows)
+        float ps = 0.f, ns = 0.f, rr = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            ps += u[j] * f[0][j]; ns += u[j] * f[1][j];
+            rr += u[j] * u[j] + f[0][j] * f[0][j] + f[1][j] * f[1][j];
+        }
+        ps = wave_sum(ps); ns = wave_sum(ns); rr = wave_sum(rr);
+        const float x = ps - ns;
+        const float gb = -a.inv_B * sigmoid_neg_f(x);
+        if (lane == 0) {
+            a.terms[b] = logsigmoid_f(x); a.terms[a.terms_stride + b] = rr; a.terms[2 * a.terms_stride + b] = ent[0] + ent[1];
+        }
+        // backward: user row
+        const int64_t urow = iu;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            if (col) {
+                const float du = gb * (f[0][j] - f[1][j]) + a.lam * u[j];
+                atomicAdd((unsigned long long *)(a.G64 + urow * D + j * LPT + lane), (unsigned long long)__double2ll_rn((double)du * FIXED_SCALE));
+            }
+        }
+        if (lane == 0) atomicOr(a.bitmap + (urow >> 5), 1u << (urow & 31));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int sidx = 2 * tt + q;
+            const int64_t row = (int64_t)item[q] + a.n_users;
+            float dF[CPT], part = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                dF[j] = (q == 0 ? gb : -gb) * u[j] + a.lam * f[q][j];
+                part += dF[j] * (e[q][j] - pv[q][j]);
+            }
+            const bool inside = g[q] > 1e-6f && g[q] < 1.f - 1e-6f;            // the clamp passes gradient only inside its range
+            const float dent = inside ? a.ent_scale * (logf(g[q]) - logf(1.f - g[q])) : 0.f;
+            const float dlogit = (wave_sum(part) + dent) * g[q] * (1.f - g[q]) * a.inv_temp;
+            if (lane < Hg) DH[sidx * GATE_HMAX + lane] = HR[sidx * GATE_HMAX + lane] > 0.f ? dlogit * V2[lane] : 0.f;
+            if (lane == 0) DLOG[sidx] = dlogit;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int c = j * LPT + lane;
+                float die = 0.f, dip = 0.f;
+                if (col) for (int k = 0; k < Hg; k++) { const float dh = DH[sidx * GATE_HMAX + k]; die += V1p[k * V1S + c] * dh; dip += V1p[k * V1S + D + c] * dh; }
+                const float de = g[q] * dF[j] + die, dpv = (1.f - g[q]) * dF[j] + dip;
+                if (col) {
+                    DPV[sidx * D + c] = dpv;
+                    atomicAdd((unsigned long long *)(a.G64 + row * D + c), (unsigned long long)__double2ll_rn((double)de * FIXED_SCALE));
+                }
+            }
+            if (lane == 0) {
+                atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+                if (a.item_bitmap) atomicOr(a.item_bitmap + (item[q] >> 5), 1u << (item[q] & 31));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < Hp) {
+                float da = 0.f;
+                for (int c = 0; c < D; c++) da += W2p[c * W2S + lane] * DPV[sidx * D + c];
+                DA[sidx * GATE_HMAX + lane] = AA[sidx * GATE_HMAX + lane] > 0.f ? da : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: this workgroup's parameter-gradient sums over its slots, slot order fixed
+    float *out = a.partials + (int64_t)blockIdx.x * a.P;
+    for (int i = tid; i < a.P; i += 256) {
+        float v = 0.f;
+        if (i < Hp) { for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + i] * SC[sI]; }
+        else if (i < oW2) { const int k = i - Hp; for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + k]; }
+        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c] * AA[sI * GATE_HMAX + k]; }
+        else if (i < oV1) { const int c = i - ob2; for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c]; }
+        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]; }
+        else if (i < oV2) { const int jj = i - oc1; for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj]; }
+        else if (i < oc2) { const int jj = i - oV2; for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI] * HR[sI * GATE_HMAX + jj]; }
+        else { for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI]; }
+        out[i] = v;
+    }
+}
+static size_t gate_lds_bytes(int D) {
+    const size_t fl = (size_t)GATE_HMAX * (2 * D + 1) + (size_t)D * (GATE_HMAX + 1) + 2 * GATE_HMAX + D + 2 * GATE_HMAX
+                    + (size_t)GATE_S * 2 * D + 2 * GATE_S * GATE_HMAX + (size_t)GATE_S * D + 2 * GATE_S * GATE_HMAX + 2 * GATE_S;
+    return fl * sizeof(float);
+}
+
+// sum of the workgroups' partial sums in index order + torch.optim.Adam on the MLP parameters (same arithmetic as
+// spmm_epilogue's); grad_out keeps the reduced gradient (tests, inspection)
+struct GateAdamArgs {
+    const float *partials; int32_t n_part, P;
+    float *params, *m, *v, *grad_out;
+    float step_size, bc2_sqrt, w1, beta2, omb2, eps;
+};
+__global__ void __launch_bounds__(256) k_gate_adam(GateAdamArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    float g = 0.f;
+    for (int q = 0; q < a.n_part; q++) g += a.partials[(int64_t)q * a.P + i];
+    a.grad_out[i] = g;
+    float m = a.m[i], v = a.v[i], p = a.params[i];
+    m = m + a.w1 * (g - m);
+    v = v * a.beta2 + (a.omb2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+    a.params[i] = p; a.m[i] = m; a.v[i] = v;
+}
+
+// T = mean of the K+1 layers (the stack + mean of computer(), model.py:221-222): user rows to out_u, item rows to out_i
+// (two destinations: with item-item smoothing the item block is an SpMM input and its result lands beside the users)
+struct MeanSplitArgs {
+    const float *X0; const void *Xl[LGCN_MAX_LAYERS + 1]; int K;
+    float *out_u, *out_i; int64_t n4_users, n4;      // 4-element pieces: of the user block, of the whole table
+};
+template <typename TI>
+__global__ void __launch_bounds__(256) k_mean_layers(MeanSplitArgs a) {
+    const float div = (float)(a.K + 1);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = load4(a.X0 + i * 4);
+        for (int k = 1; k <= a.K; k++) s += load4((const TI *)a.Xl[k] + i * 4);
+        store4((i < a.n4_users ? a.out_u : a.out_i) + i * 4, s / div);
+    }
+}
+// flag the rows [lo, hi) in a row bitmap (item-item smoothing makes every item row of Gs non-zero)
+__global__ void __launch_bounds__(256) k_flag_range(uint32_t *bm, int64_t lo, int64_t hi) {
+    const int64_t wlo = lo >> 5, whi = (hi + 31) >> 5;
+    for (int64_t wd = wlo + (int64_t)blockIdx.x * 256 + threadIdx.x; wd < whi; wd += (int64_t)gridDim.x * 256) {
+        uint32_t m = 0xffffffffu;
+        if (wd == (lo >> 5)) m &= 0xffffffffu << (lo & 31);
+        if (wd == (hi >> 5)) m &= (hi & 31) ? (0xffffffffu >> (32 - (hi & 31))) : 0u;
+        if (m == 0xffffffffu) bm[wd] = m; else if (m) atomicOr(bm + wd, m);
+    }
+}
+
 // slot -> destination row of the global batch (-1: the slot's triplet has a bad id)
 __device__ __forceinline__ int64_t slot_row(int c, int b, const int32_t *users, const int32_t *pos,
                                             const int32_t *neg, int32_t n_users, int64_t N) {
@@ -1022,6 +1285,7 @@ struct SlotArgs {
     const float *gathered; int32_t shard; int32_t world;   // DP scatter
     int32_t skip_rank;                                     // DP scatter: this rank's own block is in G64 already (-1: none)
     const float *terms; float *loss_out; float decay;
+    float ent_coeff;
 };
 
 // DP: order-independent scatter of every rank's gradient rows into G64 (+ row flags)
@@ -1087,7 +1351,7 @@ __global__ void __launch_bounds__(256) k_finish(SlotArgs a) {
     }
     // the same single-wave, fixed-order reduction as the fused finish of the last SpMM: identical bits
     if (blockIdx.x == 0 && threadIdx.x < 64)
-        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, (int)threadIdx.x);
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, (int)threadIdx.x, a.ent_coeff);
 }
 
 __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, const int64_t *perm, int64_t T,
@@ -1137,6 +1401,18 @@ static int launch_spmm(const SpmmArgs &a, int d, int x_dtype, int y_dtype, hipSt
     case 64: return launch_spmm_d<64, MODE>(a, x_dtype, y_dtype, st);
     case 128: return launch_spmm_d<128, MODE>(a, x_dtype, y_dtype, st);
     case 256: return launch_spmm_d<256, MODE>(a, x_dtype, y_dtype, st);
+    }
+    lgcn_set_error("embedding dim must be 32, 64, 128 or 256");
+    return 3;
+}
+
+// Y = selfX + A X on fp32 tables (item-item smoothing): only the fp32 instance exists
+static int launch_spmm_addself(const SpmmArgs &a, int d, hipStream_t st) {
+    switch (d) {
+    case 32: launch_spmm_t<32, float, float, M_ADDSELF>(a, st); return 0;
+    case 64: launch_spmm_t<64, float, float, M_ADDSELF>(a, st); return 0;
+    case 128: launch_spmm_t<128, float, float, M_ADDSELF>(a, st); return 0;
+    case 256: launch_spmm_t<256, float, float, M_ADDSELF>(a, st); return 0;
     }
     lgcn_set_error("embedding dim must be 32, 64, 128 or 256");
     return 3;
@@ -1477,6 +1753,12 @@ struct lgcn_ctx {
     int64_t hub_rows;             // rows in that plan
     bool dp_local;                // data parallel (rows): part 1 also adds this rank's own rows into G64, part 2 scatters the others'
     int dp_rank;                  // rank of the last part 1
+    // optional branches of the fork (popularity gate / item-item smoothing): the step runs on ONE final table
+    bool variant;                 // either branch is on
+    float *tvar;                  // [N,d] fp32 final propagated table T (library-owned)
+    uint32_t *item_bitmap;        // [ceil(m_items/32)] items named by the batch (item-item backward), library-owned
+    float *gate_partials;         // [n_wg, P] parameter-gradient partial sums (library-owned)
+    int32_t gate_P, gate_wgs;
 };
 // a multi-step call: nobody but this library touches E0 between its steps
 struct LoopScope {
@@ -1496,6 +1778,16 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (check_dtype(c.act_dtype)) return 3;
     if (c.n_users <= 0 || c.n_users >= c.graph->n_rows || c.max_batch <= 0) { lgcn_set_error("lgcn_ctx_create: bad sizes"); return 3; }
     if (c.d > c.graph->d_max) { lgcn_set_error("lgcn_ctx_create: d exceeds the graph's d_max"); return 3; }
+    const bool gate = c.item_pop != nullptr, smooth = c.i2i != nullptr;
+    if (gate || smooth) {
+        if (!c.dense_last) { lgcn_set_error("lgcn_ctx_create: the optional branches need dense_last = 1 (every layer propagated densely)"); return 3; }
+        const int64_t m_items = c.graph->n_rows - c.n_users;
+        if (smooth && (!c.i2i_t || c.i2i->n_rows != m_items || c.i2i_t->n_rows != m_items || c.i2i->d_max < c.d || c.i2i_t->d_max < c.d)) {
+            lgcn_set_error("lgcn_ctx_create: i2i / i2i_t must be [m_items, m_items] graphs with d_max >= d"); return 3; }
+        if (gate && (!c.gate_params || !c.gate_adam_m || !c.gate_adam_v || !c.gate_grad || c.pop_hidden < 1 || c.pop_hidden > GATE_HMAX ||
+                     c.gate_hidden < 1 || c.gate_hidden > GATE_HMAX || c.d > 128 || !(c.pop_gate_temp > 0.f))) {
+            lgcn_set_error("lgcn_ctx_create: popularity gate needs its parameter / Adam buffers, hidden sizes in 1..64, d <= 128, temperature > 0"); return 3; }
+    }
     lgcn_ctx *x = new (std::nothrow) lgcn_ctx;
     if (!x) { lgcn_set_error("out of memory"); return 4; }
     x->c = c; x->step = 0; x->N = c.graph->n_rows;
@@ -1507,8 +1799,19 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
     x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
     x->hub_graph = nullptr; x->hub_nnz = 0; x->hub_rows = 0;
+    x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_P = 0; x->gate_wgs = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
+    if (ok && x->variant) ok = hipMalloc((void **)&x->tvar, gbytes) == hipSuccess;
+    if (ok && smooth) {
+        const size_t wb = sizeof(uint32_t) * (size_t)((x->N - c.n_users + 31) / 32);
+        ok = hipMalloc((void **)&x->item_bitmap, wb) == hipSuccess && hipMemset(x->item_bitmap, 0, wb) == hipSuccess;
+    }
+    if (ok && gate) {
+        x->gate_P = 2 * c.pop_hidden + c.d * c.pop_hidden + c.d + 2 * c.d * c.gate_hidden + 2 * c.gate_hidden + 1;
+        x->gate_wgs = (c.max_batch + GATE_TPB - 1) / GATE_TPB;
+        ok = hipMalloc((void **)&x->gate_partials, sizeof(float) * (size_t)x->gate_wgs * x->gate_P) == hipSuccess;
+    }
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
     if (ok && !c.dense_last) {
         // Rows too long for one workgroup (a 800 000-neighbour item of the 10M x 1M graph kept ONE k_triplet workgroup busy
@@ -1533,6 +1836,9 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     }
     if (!ok) {
         if (x->g32) (void)hipFree(x->g32);
+        if (x->tvar) (void)hipFree(x->tvar);
+        if (x->item_bitmap) (void)hipFree(x->item_bitmap);
+        if (x->gate_partials) (void)hipFree(x->gate_partials);
         if (x->e0b) (void)hipFree(x->e0b);
         if (x->hub_graph) lgcn_graph_destroy(x->hub_graph);
         delete x;
@@ -1545,6 +1851,9 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
 extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->g32) (void)hipFree(ctx->g32);
+    if (ctx->tvar) (void)hipFree(ctx->tvar);
+    if (ctx->item_bitmap) (void)hipFree(ctx->item_bitmap);
+    if (ctx->gate_partials) (void)hipFree(ctx->gate_partials);
     if (ctx->e0b) (void)hipFree(ctx->e0b);
     if (ctx->hub_graph) lgcn_graph_destroy(ctx->hub_graph);
     delete ctx;
@@ -1632,6 +1941,66 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     return 0;
 }
 
+// The optional branches' forward tail and loss: T = mean of the K+1 dense layers, item-item smoothing, then the loss on the
+// ONE final table (popularity gate inside k_triplet_gate).  Single GPU, whole batch.
+static int run_variant_loss(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B, hipStream_t st) {
+    const lgcn_train_config &c = x->c;
+    const int64_t m_items = x->N - c.n_users;
+    float *items_mean = c.i2i ? x->g32 : x->tvar;           // with smoothing the item block of T is an SpMM input first
+    MeanSplitArgs m{};
+    m.X0 = c.E0; m.K = c.K; m.out_u = x->tvar; m.out_i = items_mean;
+    for (int k = 1; k <= c.K; k++) m.Xl[k] = x->act[k];
+    m.n4_users = (int64_t)c.n_users * c.d / 4; m.n4 = x->N * c.d / 4;
+    {
+        const int64_t blocks = (m.n4 + 255) / 256;
+        const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+        if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_mean_layers<float>), dim3(grid), dim3(256), 0, st, m);
+        else hipLaunchKernelGGL((k_mean_layers<bf16_t>), dim3(grid), dim3(256), 0, st, m);
+    }
+    if (c.i2i) {            // items = T_items + (alpha I2I) T_items   (model.py:228-229)
+        { int rc0 = graph_acquire(c.i2i, st); if (rc0) return rc0; }
+        SpmmArgs h = graph_spmm(c.i2i);
+        h.X = x->g32 + (int64_t)c.n_users * c.d; h.selfX = (const float *)h.X; h.Y = x->tvar + (int64_t)c.n_users * c.d; h.remap = c.xcd_remap;
+        int rc = launch_spmm_addself(h, c.d, st);
+        if (rc) return rc;
+        HIP_OK(hipMemsetAsync(x->item_bitmap, 0, sizeof(uint32_t) * (size_t)((m_items + 31) / 32), st));
+    }
+    uint32_t *bm = c.bitmap + x->flip * x->bm_words, *stale = c.bitmap + (x->flip ^ 1) * x->bm_words;
+    if (c.item_pop) {
+        GateArgs g{};
+        g.E = x->tvar; g.item_pop = c.item_pop; g.params = c.gate_params; g.partials = x->gate_partials;
+        g.Hp = c.pop_hidden; g.Hg = c.gate_hidden; g.P = x->gate_P;
+        g.inv_temp = 1.0f / c.pop_gate_temp; g.ent_scale = c.gate_entropy_coeff / (float)(2 * B);
+        g.n_users = c.n_users; g.N = x->N; g.users = users; g.pos = pos; g.neg = neg; g.B = B;
+        g.inv_B = 1.0f / (float)B; g.lam = c.decay / (float)B;
+        g.G64 = (long long *)c.G64; g.bitmap = bm; g.item_bitmap = c.i2i ? x->item_bitmap : nullptr;
+        g.stale_bitmap = stale; g.bitmap_words = x->bm_words; g.terms = c.terms; g.terms_stride = B; g.err = c.err;
+        const unsigned grid = (unsigned)((B + GATE_TPB - 1) / GATE_TPB);
+        const size_t lds = gate_lds_bytes(c.d);
+        switch (c.d) {
+        case 32: HIP_OK(hipFuncSetAttribute((const void *)k_triplet_gate<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                 hipLaunchKernelGGL((k_triplet_gate<32>), dim3(grid), dim3(256), lds, st, g); break;
+        case 64: HIP_OK(hipFuncSetAttribute((const void *)k_triplet_gate<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                 hipLaunchKernelGGL((k_triplet_gate<64>), dim3(grid), dim3(256), lds, st, g); break;
+        case 128: HIP_OK(hipFuncSetAttribute((const void *)k_triplet_gate<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                 hipLaunchKernelGGL((k_triplet_gate<128>), dim3(grid), dim3(256), lds, st, g); break;
+        default: lgcn_set_error("popularity gate: embedding dim must be 32, 64 or 128"); return 3;
+        }
+    } else {
+        BprArgs a{};
+        a.X0 = x->tvar; a.K = 0; a.dense_last = 1;            // e = the row of the final table
+        a.n_users = c.n_users; a.N = x->N; a.users = users; a.pos = pos; a.neg = neg; a.B_local = B; a.shard = B;
+        a.inv_B = 1.0f / (float)B; a.lam = c.decay / (float)B;
+        a.G64 = (long long *)c.G64; a.bitmap = bm; a.stale_bitmap = stale; a.bitmap_words = x->bm_words;
+        a.item_bitmap = x->item_bitmap; a.terms = c.terms; a.err = c.err; a.terms_off = 0; a.terms_stride = B;
+        DISPATCH_D(c.d, {
+            const int tpb = 256 / (D < 64 ? D : 64);
+            hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, st, a);
+        });
+    }
+    return 0;
+}
+
 static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
                           const float *gathered, int32_t shard, int32_t world, float *loss_out) {
     const lgcn_train_config &c = x->c;
@@ -1640,6 +2009,7 @@ static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t
     s.G64 = (long long *)c.G64; s.G32 = x->g32; s.div = (float)(c.K + 1);
     s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
     s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay; s.skip_rank = -1;
+    s.ent_coeff = c.item_pop ? c.gate_entropy_coeff : 0.f;
     return s;
 }
 static unsigned scatter_grid(const lgcn_ctx *x, int32_t B) {      // k_scatter: one lane group of min(d, 64) lanes per slot
@@ -1667,6 +2037,20 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
     if (first) {        // every contribution is in G64 by now: convert the batch rows once
         SlotArgs s = slot_args(x, users, pos, neg, B, gathered, shard, 1, loss_out);
         DISPATCH_D(c.d, hipLaunchKernelGGL((k_g32<D>), dim3(slot_grid(x, B)), dim3(256), 0, st, s));
+        if (x->variant && c.i2i) {
+            // backward of the smoothing: Gs_items <- Gs_items + (alpha I2I)^T Gs_items, a sparse-input SpMM on the item block; the
+            // result is dense, so every item row of Gs counts as non-zero from here on
+            { int rc0 = graph_acquire(c.i2i_t, st); if (rc0) return rc0; }
+            const int64_t ioff = (int64_t)c.n_users * c.d, m_items = x->N - c.n_users;
+            SpmmArgs h = graph_spmm(c.i2i_t);
+            h.G32 = x->g32 + ioff; h.bitmap = x->item_bitmap; h.Y = x->tvar + ioff; h.div = (float)(c.K + 1); h.remap = c.xcd_remap;
+            int rc = launch_spmm<M_SPARSE | M_ADDG>(h, c.d, LGCN_F32, LGCN_F32, st);
+            if (rc) return rc;
+            HIP_OK(hipMemcpyAsync(x->g32 + ioff, x->tvar + ioff, sizeof(float) * (size_t)m_items * c.d, hipMemcpyDeviceToDevice, st));
+            const int64_t words = (x->N + 31) / 32;
+            hipLaunchKernelGGL(k_flag_range, dim3((unsigned)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64)), dim3(256), 0, st,
+                               c.bitmap + x->flip * x->bm_words, (int64_t)c.n_users, x->N);
+        }
     }
     SpmmArgs a = base_spmm(x);
     a.X = first ? nullptr : bwd_buffer(x, k + 1);
@@ -1683,7 +2067,7 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
         a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
         if (!first && fused_finish) {       // K >= 2: this launch also cleans the workspace and reduces the loss
             a.clear = 1; a.terms = c.terms; a.gathered = gathered; a.loss_out = loss_out;
-            a.B = B; a.shard = shard; a.decay = c.decay;
+            a.B = B; a.shard = shard; a.decay = c.decay; a.ent_coeff = c.item_pop ? c.gate_entropy_coeff : 0.f;
         }
     }
     const int prev_dt = first ? LGCN_F32 : c.act_dtype;
@@ -1710,6 +2094,15 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         int rc = backward_layer(x, k, users, pos, neg, B, gathered, shard, loss_out, true, st);
         if (rc) return rc;
     }
+    if (x->variant && c.item_pop) {          // torch.optim.Adam on the gate's MLP parameters, same step count as the tables
+        GateAdamArgs ga{};
+        ga.partials = x->gate_partials; ga.n_part = (B + GATE_TPB - 1) / GATE_TPB; ga.P = x->gate_P;
+        ga.params = c.gate_params; ga.m = c.gate_adam_m; ga.v = c.gate_adam_v; ga.grad_out = c.gate_grad;
+        const double bc1 = 1.0 - pow(c.beta1, (double)x->step), bc2 = 1.0 - pow(c.beta2, (double)x->step);
+        ga.step_size = (float)(c.lr / bc1); ga.bc2_sqrt = (float)sqrt(bc2);
+        ga.w1 = (float)(1.0 - c.beta1); ga.beta2 = (float)c.beta2; ga.omb2 = (float)(1.0 - c.beta2); ga.eps = (float)c.eps;
+        hipLaunchKernelGGL(k_gate_adam, dim3((unsigned)((x->gate_P + 255) / 256)), dim3(256), 0, st, ga);
+    }
     if (c.K >= 2) { x->flip ^= 1; return 0; }       // next step flags rows in the other bitmap
     DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(sgrid), dim3(256), 0, st, s));
     return 0;
@@ -1728,7 +2121,9 @@ extern "C" int lgcn_train_step(lgcn_ctx *x, const int32_t *users, const int32_t 
     if (!loss_out) { lgcn_set_error("train step: loss_out is null"); return 3; }
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, false, st))) return rc;
+    if (x->variant) rc = run_variant_loss(x, users, pos, neg, B, st);
+    else rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, false, st);
+    if (rc) return rc;
     if ((rc = run_backward(x, users, pos, neg, B, nullptr, B, 1, loss_out, st))) return rc;
     HIP_OK(hipGetLastError());
     return 0;
@@ -1753,6 +2148,7 @@ extern "C" int lgcn_train_step_dp_part1(lgcn_ctx *x, const int32_t *users, const
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
     if (!x->c.contrib) { lgcn_set_error("dp step: cfg.contrib exchange buffer missing"); return 3; }
+    if (x->variant) { lgcn_set_error("dp step: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("dp step: bad world/rank"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
     const int32_t b_off = rank * shard;
@@ -1772,6 +2168,7 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
                                               int32_t B_global, int32_t world, int32_t rank, void *stream) {
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
+    if (x->variant) { lgcn_set_error("dp step: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("dp step: bad world/rank"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
     const int32_t b_off = rank * shard;
@@ -1812,6 +2209,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
                              int32_t B_global, int32_t world, int32_t rank, const float *gathered, float *loss_out, void *stream) {
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
+    if (x->variant) { lgcn_set_error("lgcn_rs_phase: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
     const lgcn_train_config &c = x->c;
     hipStream_t st = (hipStream_t)stream;
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("lgcn_rs_phase: bad world/rank"); return 3; }

@@ -136,6 +136,7 @@ class LightGCN(nn.Module):
             raise ValueError("adjacency shape does not match n_users + m_items")
         if len(self._adj.indices) and (self._adj.indices.min() < 0 or self._adj.indices.max() >= N):
             raise ValueError("adjacency column index out of range")
+        self._gate_flat = None      # the eight MLP tensors of the gate in ONE buffer (what the fused step reads / updates)
         self._Graph = None
         self._dev = None            # device-side state (graph, workspace, context)
         self._cache = None          # propagated embeddings memoised between invalidate_cache() calls
@@ -174,6 +175,45 @@ class LightGCN(nn.Module):
                 self._table[:self.n_users].copy_(u.data)
                 self._table[self.n_users:].copy_(i.data)
             self._rebind()
+        if self.use_pop_gate:
+            self._pack_gate()
+
+    def gate_parameters(self):
+        """The gate's eight tensors in torch's named_parameters order (pop_mlp.0.weight ... gate_mlp.2.bias)."""
+        return list(self.pop_mlp.parameters()) + list(self.gate_mlp.parameters())
+
+    def _pack_gate(self):
+        """The fused step reads and updates the gate's MLPs as ONE fp32 buffer (include/lgcn_hip.h: gate_params): keep the
+        nn.Linear parameters views of it.  Returns True when the buffer was (re)made -- a context bound to the old one is stale."""
+        ps = self.gate_parameters()
+        flat, off, ok = self._gate_flat, 0, self._gate_flat is not None
+        for prm in ps:
+            ok = ok and prm.device == flat.device and prm.data_ptr() == flat.data_ptr() + 4 * off and prm.is_contiguous()
+            off += prm.numel()
+        if ok:
+            return False
+        flat = torch.cat([prm.data.reshape(-1).float() for prm in ps]).contiguous()
+        off = 0
+        for prm in ps:
+            prm.data = flat[off:off + prm.numel()].view(prm.shape)
+            off += prm.numel()
+        self._gate_flat = flat
+        if self._dev is not None and self._dev.get('ctx'):
+            _lib.load().lgcn_ctx_destroy(self._dev['ctx'])
+            self._dev['ctx'] = None
+        return True
+
+    @property
+    def fused_variants(self):
+        """The optional branches run inside the fused HIP step (default) unless --fused_variants 0 asks for the autograd
+        path or the gate's shape is outside what k_triplet_gate holds in LDS (hidden sizes <= 64, d <= 128)."""
+        if not self.has_variants:
+            return False
+        if not int(self.config.get('fused_variants', 1)):
+            return False
+        if self.use_pop_gate and (self.latent_dim > 128 or self.pop_hidden > 64 or self.gate_hidden > 64 or self.pop_gate_temp <= 0):
+            return False
+        return True
 
     @property
     def Graph(self):
@@ -190,7 +230,7 @@ class LightGCN(nn.Module):
             self._dev['graph_rs'].close()
         if self._dev is not None and self._dev.get('graph') is not None:
             self._dev['graph'].close()
-        for key in ('i2i', 'i2i_t'):
+        for key in ('i2i', 'i2i_t', 'i2i_s', 'i2i_ts'):
             if self._dev is not None and self._dev.get(key) is not None:
                 self._dev[key].close()
         self._dev = None
@@ -254,10 +294,13 @@ class LightGCN(nn.Module):
             st['adam_m'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
             st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
         dense_last = self._dense_last(int(self.config.get('bpr_batch_size', max_batch)))     # the configured batch, not this context's capacity
+        variants = self.fused_variants
+        if variants:
+            dense_last = True       # the optional branches score on the layer mean of EVERY row (model.py:221-229)
         st['act'] = torch.zeros(max(1, K if dense_last else K - 1), N, d, dtype=tdt, device=dev)
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
         st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
-        st['terms'] = torch.zeros(2 * max_batch, dtype=torch.float32, device=dev)
+        st['terms'] = torch.zeros(3 * max_batch, dtype=torch.float32, device=dev)
         shard = (max_batch + dp_world - 1) // dp_world
         st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -277,6 +320,26 @@ class LightGCN(nn.Module):
         cfg.dense_last = int(dense_last)
         cfg.hub_nnz = int(self.config.get('hub_nnz', 0))          # 0: library default; < 0: off
         cfg.hub_chunk = int(self.config.get('hub_chunk', 0))
+        if variants and self.i2i_active:
+            # the fused step's graphs hold alpha * I2I and its transpose (model.py:228-229 scales after the product)
+            for key, mat in (('i2i_s', self._i2i), ('i2i_ts', self._i2i.T.tocsr())):
+                if key not in st:
+                    mat = mat.tocsr().astype(np.float32)
+                    mat.sort_indices()
+                    st[key] = _lib.Graph(torch.from_numpy(mat.indptr.astype(np.int32)).to(dev), torch.from_numpy(mat.indices.astype(np.int32)).to(dev),
+                                         torch.from_numpy((np.float32(self.i2i_alpha) * mat.data).astype(np.float32)).to(dev), d_max=d)
+            cfg.i2i, cfg.i2i_t = st['i2i_s'].handle, st['i2i_ts'].handle
+        if variants and self.use_pop_gate:
+            self._pack_gate()
+            P = self._gate_flat.numel()
+            for key in ('gate_m', 'gate_v', 'gate_grad'):
+                if key not in st or st[key].numel() != P:
+                    st[key] = torch.zeros(P, dtype=torch.float32, device=dev)
+            st['item_pop'] = self.item_pop_scalar.to(device=dev, dtype=torch.float32).contiguous()
+            cfg.item_pop, cfg.gate_params = st['item_pop'].data_ptr(), self._gate_flat.data_ptr()
+            cfg.gate_adam_m, cfg.gate_adam_v, cfg.gate_grad = st['gate_m'].data_ptr(), st['gate_v'].data_ptr(), st['gate_grad'].data_ptr()
+            cfg.pop_hidden, cfg.gate_hidden = self.pop_hidden, self.gate_hidden
+            cfg.gate_entropy_coeff, cfg.pop_gate_temp = self.gate_entropy_coeff, self.pop_gate_temp
         st['dense_last'] = dense_last
         h = C.c_void_p()
         _lib.check(lib.lgcn_ctx_create(C.byref(cfg), C.byref(h)), "lgcn_ctx_create")
@@ -436,9 +499,9 @@ class LightGCN(nn.Module):
     def fused_step(self, users, pos, neg, loss_out=None, lr=None):
         """One BPRLoss.stageOne (utils.py:53-64) in the HIP kernels.  Returns a device
         tensor [3] = (bpr + decay*reg, bpr, reg); no host synchronisation."""
-        if self.has_variants:
-            raise RuntimeError("the fused step covers the default model; with the popularity gate or item-item smoothing "
-                               "use BPRLoss.stageOne (autograd path over the same HIP propagation kernels)")
+        if self.has_variants and not self.fused_variants:
+            raise RuntimeError("this configuration of the popularity gate / item-item smoothing is outside the fused step "
+                               "(--fused_variants 0, or gate hidden sizes > 64 / d > 128): use BPRLoss.stageOne (autograd path)")
         dev = self._table.device
         users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
         B = int(users.numel())
@@ -457,8 +520,8 @@ class LightGCN(nn.Module):
     def fused_epoch(self, users, pos, neg, batch_size, lr=None):
         """The loop of main.py:223-225 over already-shuffled device id arrays, one C call.
         Returns a device tensor [steps,3] of per-step (loss, bpr, reg)."""
-        if self.has_variants:
-            raise RuntimeError("fused_epoch covers the default model; loop BPRLoss.stageOne for the optional branches")
+        if self.has_variants and not self.fused_variants:
+            raise RuntimeError("this configuration of the optional branches is outside the fused step: loop BPRLoss.stageOne")
         dev = self._table.device
         users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
         T = int(users.numel())

@@ -71,6 +71,9 @@ def build_parser():
     p.add_argument('--dense_last', type=str, default='auto', choices=['auto', '0', '1'],
                    help='NEW: last forward layer on the batch rows only (0), densely (1), or whichever is cheaper for '
                         'this graph and batch size (auto)')
+    p.add_argument('--fused_variants', type=int, default=1,
+                   help='NEW: 1 = --use_pop_gate / --use_item_item train inside the fused HIP step; 0 = autograd path (torch MLPs '
+                        'and torch Adam around the HIP propagation kernels)')
     p.add_argument('--hub_nnz', type=int, default=0,
                    help='NEW: graph rows with more non-zeros than this get their last-layer row from a whole-chip SpMM once per '
                         'step instead of from every triplet that names them (0 = library default 131072, < 0 = off)')

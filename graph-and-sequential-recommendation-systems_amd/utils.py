@@ -55,6 +55,14 @@ class _AdamView(optim.Adam):
             s = self.state[p]
             s['step'] = torch.tensor(step, dtype=torch.float32)
             s['exp_avg'], s['exp_avg_sq'] = st['adam_m'][sl], st['adam_v'][sl]
+        if getattr(m, 'use_pop_gate', False) and 'gate_m' in st:       # the gate's MLPs: views of the fused step's flat Adam state
+            off = 0
+            for p in m.gate_parameters():
+                s = self.state[p]
+                s['step'] = torch.tensor(step, dtype=torch.float32)
+                s['exp_avg'] = st['gate_m'][off:off + p.numel()].view(p.shape)
+                s['exp_avg_sq'] = st['gate_v'][off:off + p.numel()].view(p.shape)
+                off += p.numel()
 
     def state_dict(self):
         self._sync_from_kernel()
@@ -73,6 +81,14 @@ class _AdamView(optim.Adam):
                     st['adam_m'][sl].copy_(s['exp_avg'])
                     st['adam_v'][sl].copy_(s['exp_avg_sq'])
                     step = int(float(s['step']))
+            if getattr(m, 'use_pop_gate', False) and 'gate_m' in st:
+                off = 0
+                for p in m.gate_parameters():
+                    s = self.state.get(p, {})
+                    if 'exp_avg' in s:
+                        st['gate_m'][off:off + p.numel()].copy_(s['exp_avg'].reshape(-1))
+                        st['gate_v'][off:off + p.numel()].copy_(s['exp_avg_sq'].reshape(-1))
+                    off += p.numel()
         _lib.load().lgcn_ctx_set_step(st['ctx'], step)
         self._sync_from_kernel()
 
@@ -88,9 +104,10 @@ class BPRLoss:
         self.model = recmodel
         self.weight_decay = config['decay']
         self.lr = config['lr']
-        # the optional branches (popularity gate, item-item smoothing) train through autograd and a plain
-        # torch Adam over ALL parameters -- the reference's own sequence, utils.py:53-64
-        self.fused = not getattr(recmodel, 'has_variants', False)
+        # the optional branches (popularity gate, item-item smoothing) run inside the fused step too (model.fused_variants);
+        # --fused_variants 0 (or a gate shape outside the kernel's limits) trains them through autograd and a plain torch
+        # Adam over ALL parameters -- the reference's own sequence, utils.py:53-64
+        self.fused = (not getattr(recmodel, 'has_variants', False)) or bool(getattr(recmodel, 'fused_variants', False))
         if self.fused:
             self.opt = _AdamView(recmodel.parameters(), lr=self.lr).bind(recmodel)
         else:

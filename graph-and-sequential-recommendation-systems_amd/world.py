@@ -103,6 +103,7 @@ def configure(argv=None):
     config['gpu_sampler'] = args.gpu_sampler
     config['dense_last'] = args.dense_last
     config['hub_nnz'] = args.hub_nnz
+    config['fused_variants'] = args.fused_variants
     device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
     return config
 

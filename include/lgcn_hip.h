@@ -178,6 +178,28 @@ typedef struct {
      * rows (0 = default 2048).  Neither changes the algorithm, only who sums a hub row (fp32 summation order). */
     int32_t hub_nnz;
     int32_t hub_chunk;
+    /* ---- the fork's optional branches (all NULL / 0: the default model).  With either one on, the step propagates every
+     * layer densely (dense_last must be 1), forms the layer mean T, and runs the loss on ONE final table.
+     * Item-item smoothing, model.py:99-109,228-229: items = T_items + alpha * (I2I @ T_items).  i2i / i2i_t: graphs over the
+     * m_items item rows ([m_items, m_items]) holding alpha * I2I and its transpose (the caller scales the values).      */
+    const lgcn_graph *i2i;
+    const lgcn_graph *i2i_t;
+    /* Popularity gate, model.py:66-96,139-157,176-181.  gate_params: ONE fp32 buffer holding the eight tensors of pop_mlp
+     * and gate_mlp back to back in torch's named_parameters order and torch.nn.Linear layouts:
+     *   pop_mlp.0.weight [Hp,1] | pop_mlp.0.bias [Hp] | pop_mlp.2.weight [d,Hp] | pop_mlp.2.bias [d] |
+     *   gate_mlp.0.weight [Hg,2d] | gate_mlp.0.bias [Hg] | gate_mlp.2.weight [1,Hg] | gate_mlp.2.bias [1]
+     * (P = 2 Hp + d Hp + d + 2 d Hg + 2 Hg + 1 floats); gate_adam_m / gate_adam_v / gate_grad: [P] each (Adam state of those
+     * parameters, zero-initialised; the last reduced gradient, for inspection).  Hp, Hg <= 64, d <= 128.
+     * terms must then hold 3 * max_batch floats (third block: the gates' entropy per triplet).                         */
+    const float *item_pop;      /* [m_items] item_pop_scalar, or NULL: no gate */
+    float *gate_params;
+    float *gate_adam_m;
+    float *gate_adam_v;
+    float *gate_grad;
+    int32_t pop_hidden;         /* Hp */
+    int32_t gate_hidden;        /* Hg */
+    float gate_entropy_coeff;
+    float pop_gate_temp;
 } lgcn_train_config;
 
 /* Besides the caller's workspace the context owns device allocations made here with hipMalloc and released by

@@ -611,13 +611,19 @@ def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act, hub):
     m.check_device_errors()
 
 
+@pytest.mark.parametrize("path", ["fused", "autograd"])
 @pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
-def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag):
+def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag, path):
     """the fork's popularity gate (model.py:66-96,139-157,176-181) and item-item smoothing
     (model.py:99-109,228-229) against fixtures captured from the reference itself on the tiny dataset
     (tests/golden/make_golden.py tiny_gate / tiny_i2i / tiny_gate_i2i): initial parameters bit for bit (same
     modules built in the same order from seed 2020), computer(), ratings, Test metrics, bpr_loss and the
-    gradient of EVERY parameter, then three stageOne steps (torch Adam over all parameters) and the metrics after."""
+    gradient of EVERY parameter, then three stageOne steps and the metrics after.
+    path = "fused": the branches run INSIDE the fused HIP step (k_mean_layers, the item-item SpMMs, k_triplet_gate,
+    k_gate_adam): loss / reg of the reference's first batch, the gradient of every MLP parameter (the step's reduced
+    gradient buffer) against the reference's autograd gradients, the three steps' losses and EVERY parameter after them,
+    optimizer state in torch-Adam format.  path = "autograd": --fused_variants 0, the reference's own sequence (torch
+    MLPs, torch Adam) around the HIP propagation kernels."""
     gz = np.load(os.path.join(tiny.dir, f"golden_{tag}.npz"))
     meta = json.load(open(os.path.join(tiny.dir, f"golden_{tag}.json")))
     d = os.path.join(str(tmp_path), "tiny_" + tag)
@@ -630,12 +636,15 @@ def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag):
     w.config.update({'lightGCN_n_layers': meta["K"], 'latent_dim_rec': meta["d"], 'bpr_batch_size': meta["B"], 'decay': meta["decay"],
                      'lr': meta["lr"], 'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"],
                      'i2i_path': os.path.join(tiny.dir, "i2i_tiny.npz") if meta["use_item_item"] else None, 'i2i_alpha': meta["i2i_alpha"],
-                     'eval_fused': 1})
+                     'eval_fused': 1, 'fused_variants': 1 if path == "fused" else 0})
     w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
     ds = pkg.dataloader.Loader(w.config, path=d)
-    pkg.utils.set_seed(meta["seed"])
-    m = pkg.model.LightGCN(w.config, ds).to(DEV)
-    assert m.has_variants
+
+    def fresh():
+        pkg.utils.set_seed(meta["seed"])
+        return pkg.model.LightGCN(w.config, ds).to(DEV)
+    m = fresh()
+    assert m.has_variants and m.fused_variants == (path == "fused")
     sd = m.state_dict()
     assert sorted(sd) == sorted(k[3:] for k in gz.files if k.startswith("P0."))          # the reference's keys
     for k, v in sd.items():
@@ -653,15 +662,34 @@ def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag):
             np.testing.assert_allclose(np.asarray(r[k], np.float64), meta["test_epoch0"][k], rtol=0, atol=1e-6)
     m.train()
     b = gz["batches"]
-    loss, reg = m.bpr_loss(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
-    assert abs(float(loss) - meta["b_loss"]) < 2e-6 and abs(float(reg) - meta["b_reg"]) < 2e-6
-    m.zero_grad()
-    (loss + reg * meta["decay"]).backward()
-    for k, prm in m.named_parameters():
-        np.testing.assert_allclose(prm.grad.cpu().numpy(), gz["G0." + k], rtol=5e-4, atol=2e-8, err_msg=k)
-    m.zero_grad()
+    if path == "autograd":
+        loss, reg = m.bpr_loss(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
+        assert abs(float(loss) - meta["b_loss"]) < 2e-6 and abs(float(reg) - meta["b_reg"]) < 2e-6
+        m.zero_grad()
+        (loss + reg * meta["decay"]).backward()
+        for k, prm in m.named_parameters():
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), gz["G0." + k], rtol=5e-4, atol=2e-8, err_msg=k)
+        m.zero_grad()
+    else:
+        # the reference's first batch through the fused step: loss, reg and the MLP gradients the step itself reduced
+        out = m.fused_step(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2])).cpu().numpy()
+        assert abs(float(out[1]) - meta["b_loss"]) < 2e-6 and abs(float(out[2]) - meta["b_reg"]) < 2e-6 and abs(float(out[0]) - meta["b_total"]) < 2e-6, (out, meta["b_loss"], meta["b_reg"])
+        if meta["use_pop_gate"]:
+            gg = m._dev['gate_grad'].cpu().numpy()
+            off = 0
+            for k, prm in m.named_parameters():
+                if k.startswith("embedding"):
+                    continue
+                want = gz["G0." + k]
+                np.testing.assert_allclose(gg[off:off + want.size].reshape(want.shape), want, rtol=5e-4, atol=2e-8, err_msg=k)
+                off += want.size
+            assert off == gg.size
+        m.check_device_errors()
+        assert not bool(m._dev['G64'].any())
+        m = fresh()                            # the three recorded steps start from the initial parameters
+        m.train()
     bpr = pkg.utils.BPRLoss(m, w.config)
-    assert not bpr.fused
+    assert bpr.fused == (path == "fused")
     for i in range(3):
         l = bpr.stageOne(_dev(b[i + 1, 0]), _dev(b[i + 1, 1]), _dev(b[i + 1, 2]))
         assert abs(l - meta["step_losses"][i]) < 5e-6, (i, l, meta["step_losses"][i])
@@ -670,8 +698,17 @@ def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag):
     r = pkg.Procedure.Test(ds, m, 0)
     for k in ("precision", "recall", "ndcg"):
         np.testing.assert_allclose(np.asarray(r[k], np.float64), meta["test_after3"][k], rtol=0, atol=1e-4)
-    with pytest.raises(RuntimeError):
-        m.fused_step(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
+    if path == "fused":
+        m.check_device_errors()
+        osd = bpr.opt.state_dict()            # torch-Adam format over ALL parameters, step = 3
+        names = [k for k, _ in m.named_parameters()]
+        assert len(osd['state']) == len(names)
+        for i, k in enumerate(names):
+            assert int(osd['state'][i]['step']) == 3 and tuple(osd['state'][i]['exp_avg'].shape) == tuple(gz["P0." + k].shape), k
+            assert float(osd['state'][i]['exp_avg_sq'].abs().sum()) > 0, k
+    else:
+        with pytest.raises(RuntimeError):
+            m.fused_step(_dev(b[0, 0]), _dev(b[0, 1]), _dev(b[0, 2]))
     w.configure([])
 
 

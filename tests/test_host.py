@@ -385,7 +385,20 @@ def test_optional_branches_construct_like_the_reference(pkg, tmp_path, tag):
     for k, v in sd.items():
         assert np.array_equal(v.numpy(), gz["P0." + k]), k
     assert m.has_variants and m.i2i_active == meta["use_item_item"] and m.use_pop_gate == meta["use_pop_gate"]
-    assert not pkg.utils.BPRLoss(m, w.config).fused
+    assert m.fused_variants and pkg.utils.BPRLoss(m, w.config).fused          # the branches run inside the fused step ...
+    w.config['fused_variants'] = 0
+    assert not m.fused_variants and not pkg.utils.BPRLoss(m, w.config).fused  # ... unless the autograd path is asked for
+    w.config['fused_variants'] = 1
+    if meta["use_pop_gate"]:                  # the gate's eight tensors are views of one buffer, in named_parameters order
+        assert m._pack_gate() and not m._pack_gate()
+        flat = m._gate_flat
+        off = 0
+        for k, prm in m.named_parameters():
+            if k.startswith("embedding"):
+                continue
+            assert prm.data_ptr() == flat.data_ptr() + 4 * off and np.array_equal(prm.detach().numpy(), gz["P0." + k]), k
+            off += prm.numel()
+        assert off == flat.numel()
     w.config.update({'use_item_item': True, 'i2i_path': os.path.join(d, "missing.npz"), 'i2i_alpha': 0.5, 'use_pop_gate': False})
     m2 = pkg.model.LightGCN(w.config, ds)            # unreadable file: the reference warns and trains without it
     assert not m2.i2i_active and not m2.has_variants
