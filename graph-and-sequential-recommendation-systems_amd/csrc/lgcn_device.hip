@@ -871,6 +871,10 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
 #ifndef TRIPLET_MIN_WAVES
 #define TRIPLET_MIN_WAVES 4    /* bf16 tables: a 64-VGPR cap spills (7290 vs 7610 steps/s); fp32 tables fit 64 without (8 workgroups per CU, +0.4 %) */
 #endif
+#ifndef TRIPLET_MIN_WAVES_F32
+#define TRIPLET_MIN_WAVES_F32 7 /* fp32 tables: 72 registers without scratch; the 64-register budget of round 2 (8 workgroups per CU) spills 20 bytes
+                                   since the gather offsets became 32-bit + SGPR base (k_triplet 20.0 -> 21.9 us) */
+#endif
 #ifndef TRIPLET_U
 #define TRIPLET_U LGCN_GATHER_U   /* gathers in flight per lane in k_triplet */
 #endif
@@ -972,7 +976,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
 }
 
 template <int D, typename TI, bool BIG>
-__global__ void __launch_bounds__(256, sizeof(TI) == 4 ? 8 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
+__global__ void __launch_bounds__(256, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
     __shared__ int2 stage_lds[4][TILE_ST];
     __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
     __shared__ float base_lds[3][D];
@@ -1078,7 +1082,10 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.bitmap_words; i += (int64_t)gridDim.x * 256) a.stale_bitmap[i] = 0u;
     const int oW2 = 2 * Hp, ob2 = oW2 + D * Hp, oV1 = ob2 + D, oc1 = oV1 + Hg * D2, oV2 = oc1 + Hg, oc2 = oV2 + Hg;
+    // (the weight copies are unrolled: with one load per round trip the 8 192 + 2 048 words took a third of the launch)
+#pragma unroll 16
     for (int i = tid; i < Hg * D2; i += 256) V1p[(i / D2) * V1S + i % D2] = a.params[oV1 + i];
+#pragma unroll 8
     for (int i = tid; i < D * Hp; i += 256) W2p[(i / Hp) * W2S + i % Hp] = a.params[oW2 + i];
     if (tid < Hp) { W1[tid] = a.params[tid]; b1[tid] = a.params[Hp + tid]; }
     for (int i = tid; i < D; i += 256) b2[i] = a.params[ob2 + i];
@@ -1119,7 +1126,11 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
             for (int j = 0; j < CPT; j++) {
                 const int c = j * LPT + lane;
                 float acc = 0.f;
-                if (col) { acc = b2[c]; for (int k = 0; k < Hp; k++) acc += W2p[c * W2S + k] * AA[sidx * GATE_HMAX + k]; }
+                if (col) {
+                    acc = b2[c];
+#pragma unroll 8
+                    for (int k = 0; k < Hp; k++) acc += W2p[c * W2S + k] * AA[sidx * GATE_HMAX + k];
+                }
                 pv[q][j] = acc;
                 if (col) { IN[sidx * D2 + c] = e[q][j]; IN[sidx * D2 + D + c] = acc; }
             }
@@ -1127,7 +1138,8 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
             float hr = 0.f;
             if (lane < Hg) {
                 float h = c1[lane];
-                for (int c = 0; c < D2; c++) h += V1p[lane * V1S + c] * IN[sidx * D2 + c];
+#pragma unroll 16
+                for (int c = 0; c < D2; c++) h += V1p[lane * V1S + c] * IN[sidx * D2 + c];       // (16 LDS reads in flight, one accumulator chain)
                 hr = fmaxf(h, 0.f);
                 HR[sidx * GATE_HMAX + lane] = hr;
             }
@@ -1181,7 +1193,10 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
             for (int j = 0; j < CPT; j++) {
                 const int c = j * LPT + lane;
                 float die = 0.f, dip = 0.f;
-                if (col) for (int k = 0; k < Hg; k++) { const float dh = DH[sidx * GATE_HMAX + k]; die += V1p[k * V1S + c] * dh; dip += V1p[k * V1S + D + c] * dh; }
+                if (col) {
+#pragma unroll 8
+                    for (int k = 0; k < Hg; k++) { const float dh = DH[sidx * GATE_HMAX + k]; die += V1p[k * V1S + c] * dh; dip += V1p[k * V1S + D + c] * dh; }
+                }
                 const float de = g[q] * dF[j] + die, dpv = (1.f - g[q]) * dF[j] + dip;
                 if (col) {
                     DPV[sidx * D + c] = dpv;
@@ -1195,6 +1210,7 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
             __builtin_amdgcn_wave_barrier();
             if (lane < Hp) {
                 float da = 0.f;
+#pragma unroll 16
                 for (int c = 0; c < D; c++) da += W2p[c * W2S + lane] * DPV[sidx * D + c];
                 DA[sidx * GATE_HMAX + lane] = AA[sidx * GATE_HMAX + lane] > 0.f ? da : 0.f;
             }
@@ -1205,14 +1221,14 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
     float *out = a.partials + (int64_t)blockIdx.x * a.P;
     for (int i = tid; i < a.P; i += 256) {
         float v = 0.f;
-        if (i < Hp) { for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + i] * SC[sI]; }
-        else if (i < oW2) { const int k = i - Hp; for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + k]; }
-        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c] * AA[sI * GATE_HMAX + k]; }
-        else if (i < oV1) { const int c = i - ob2; for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c]; }
-        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]; }
-        else if (i < oV2) { const int jj = i - oc1; for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj]; }
-        else if (i < oc2) { const int jj = i - oV2; for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI] * HR[sI * GATE_HMAX + jj]; }
-        else { for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI]; }
+        if (i < Hp) { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + i] * SC[sI]; }
+        else if (i < oW2) { const int k = i - Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + k]; }
+        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c] * AA[sI * GATE_HMAX + k]; }
+        else if (i < oV1) { const int c = i - ob2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c]; }
+        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]; }
+        else if (i < oV2) { const int jj = i - oc1; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj]; }
+        else if (i < oc2) { const int jj = i - oV2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI] * HR[sI * GATE_HMAX + jj]; }
+        else { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI]; }
         out[i] = v;
     }
 }
@@ -1232,8 +1248,16 @@ struct GateAdamArgs {
 __global__ void __launch_bounds__(256) k_gate_adam(GateAdamArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
+    // the workgroups' partial sums in index order; 32 loads in flight per round trip (one load per round trip made this the
+    // longest launch of the gate step: 62 us for 256 partials)
     float g = 0.f;
-    for (int q = 0; q < a.n_part; q++) g += a.partials[(int64_t)q * a.P + i];
+    for (int q0 = 0; q0 < a.n_part; q0 += 32) {
+        float t[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) t[u] = q0 + u < a.n_part ? a.partials[(int64_t)(q0 + u) * a.P + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; u++) g += t[u];
+    }
     a.grad_out[i] = g;
     float m = a.m[i], v = a.v[i], p = a.params[i];
     m = m + a.w1 * (g - m);

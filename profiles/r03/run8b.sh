@@ -20,3 +20,8 @@ timeout -k 10 300 python tools/dp_emulate_time.py 2>> $OUT/dp.err | tail -1 | te
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5/trace -- python3 $ROOT/bench.py --workload synthetic-10m --steps 6 --warmup 2 --no_cpu_baseline > $OUT/trace_c5.log 2>&1 || echo "trace c5 failed" | tee -a $OUT/status.log
 python3 $ROOT/profiles/summarize.py $OUT/trace_c5 > $OUT/trace_synthetic-10m_fp32_summary.txt 2>&1; head -14 $OUT/trace_synthetic-10m_fp32_summary.txt | cut -c1-140
+cd $ROOT
+timeout -k 10 600 python tools/variants_time.py 2>> $OUT/variants.err | tail -1 | tee $OUT/variants_time.json | cut -c1-1200
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants/trace -- python3 $ROOT/tools/variants_time.py > $OUT/trace_variants.log 2>&1 || echo "trace variants failed" | tee -a $OUT/status.log
+python3 $ROOT/profiles/summarize.py $OUT/trace_variants > $OUT/trace_variants_summary.txt 2>&1; head -24 $OUT/trace_variants_summary.txt | cut -c1-140
