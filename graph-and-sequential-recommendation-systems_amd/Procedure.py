@@ -89,8 +89,8 @@ def BPR_train_original(dataset, recommend_model, loss_class, epoch, neg_k=1, w=N
 
     total_batch = len(users) // B + 1
     lr = bpr.opt.param_groups[0]['lr']
-    if getattr(Recmodel, 'has_variants', False):
-        # popularity gate / item-item smoothing: the reference's own loop (Procedure.py:56-66) over stageOne
+    if getattr(Recmodel, 'has_variants', False) and not getattr(Recmodel, 'fused_variants', False):
+        # popularity gate / item-item smoothing on the autograd path: the reference's own loop (Procedure.py:56-66) over stageOne
         was_lazy, bpr.lazy = bpr.lazy, True
         per = [bpr.stageOne(users[t:t + B], posItems[t:t + B], negItems[t:t + B]) for t in range(0, len(users), B)]
         bpr.lazy = was_lazy
