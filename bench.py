@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--xcd_remap", type=int, default=1)
     ap.add_argument("--dense_last", default="auto", choices=["auto", "0", "1"], help="last forward layer: on the batch rows only (0) or densely (1)")
     ap.add_argument("--row_order", default=None, choices=["natural", "rcm", "cocluster", "xcd"])
+    ap.add_argument("--hub_nnz", type=int, default=0, help="hub plan threshold of the batch-row kernel (0: library default, < 0: off)")
+    ap.add_argument("--hub_chunk", type=int, default=0, help="non-zeros per chunk of the hub plan's rows (0: library default)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the extra run with the other activation dtype")
     ap.add_argument("--spmm_only", action="store_true", help="only the dominant-kernel loop (profiling helper)")
@@ -190,7 +192,8 @@ def main():
     w = pkg.world
     w.configure(["--layer", str(K), "--recdim", str(d), "--bpr_batch", str(B), "--act_dtype", a.act_dtype,
                  "--xcd_remap", str(a.xcd_remap), "--row_order", a.row_order, "--tensorboard", "0",
-                 "--dataset", a.workload, "--dense_last", a.dense_last])
+                 "--dataset", a.workload, "--dense_last", a.dense_last, "--hub_nnz", str(a.hub_nnz)])
+    w.config['hub_chunk'] = a.hub_chunk
     import io
     import contextlib
     t_setup = time.perf_counter()
