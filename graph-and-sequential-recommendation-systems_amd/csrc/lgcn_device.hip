@@ -2129,6 +2129,11 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
     }
     if (c.K >= 2) { x->flip ^= 1; return 0; }       // next step flags rows in the other bitmap
     DISPATCH_D(c.d, hipLaunchKernelGGL((k_finish<D>), dim3(sgrid), dim3(256), 0, st, s));
+    if (x->variant && c.i2i) {
+        // K = 1 keeps ONE bitmap (k_finish clears the batch rows' words); the smoothing's backward flagged EVERY item row in it
+        // and zeroed nothing of G64 beyond the batch rows, which k_finish has just done: clear the whole bitmap
+        HIP_OK(hipMemsetAsync(c.bitmap + x->flip * x->bm_words, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
+    }
     return 0;
 }
 

@@ -712,6 +712,59 @@ def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag, path):
     w.configure([])
 
 
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+@pytest.mark.parametrize("K", [1, 2, 4])
+@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
+def test_optional_branches_fused_vs_autograd_other_depths(pkg, tiny, tmp_path, tag, K, act):
+    """The reference's fixtures pin the optional branches at K = 3, fp32.  Other depths -- K = 1 keeps ONE row bitmap and ends
+    in k_finish, K = 2 / 4 alternate two -- and bf16 activation storage: the fused step against the autograd path (the
+    reference's own sequence around the HIP propagation kernels, itself pinned at K = 3), same seed, same five batches with
+    duplicated ids: every step's loss and EVERY parameter afterwards, G64 left clean."""
+    meta = json.load(open(os.path.join(tiny.dir, f"golden_{tag}.json")))
+    d = os.path.join(str(tmp_path), f"tiny_{tag}_{K}")
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(tiny.dir, f), os.path.join(d, f))
+    w = pkg.world
+    rng = np.random.Generator(np.random.PCG64(31 * K + len(tag)))
+    ds0 = None
+    batches = None
+    out = {}
+    for fused in (1, 0):
+        w.configure([])
+        w.dataset = "tiny"
+        w.config.update({'lightGCN_n_layers': K, 'latent_dim_rec': meta["d"], 'bpr_batch_size': 64, 'decay': meta["decay"], 'lr': meta["lr"],
+                         'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"], 'act_dtype': act,
+                         'i2i_path': os.path.join(tiny.dir, "i2i_tiny.npz") if meta["use_item_item"] else None, 'i2i_alpha': meta["i2i_alpha"],
+                         'fused_variants': fused})
+        w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
+        ds = pkg.dataloader.Loader(w.config, path=d)
+        if batches is None:
+            batches = []
+            for nb in (64, 64, 33, 64, 1):
+                u = rng.integers(0, ds.n_users, nb); p = rng.integers(0, ds.m_items, nb); n = rng.integers(0, ds.m_items, nb)
+                if nb > 8:
+                    p[:4] = p[4]; n[5] = p[4]; u[7] = u[6]
+                batches.append((u, p, n))
+        pkg.utils.set_seed(meta["seed"])
+        m = pkg.model.LightGCN(w.config, ds).to(DEV)
+        m.train()
+        bpr = pkg.utils.BPRLoss(m, w.config)
+        assert bpr.fused == bool(fused)
+        losses = [bpr.stageOne(_dev(u), _dev(p), _dev(n)) for (u, p, n) in batches]
+        if fused:
+            m.check_device_errors()
+            assert not bool(m._dev['G64'].any())
+        out[fused] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()})
+        del bpr, m
+    ltol, ptol = (5e-6, 2e-5) if act == "fp32" else (2e-3, 2e-3)       # bf16: the two paths round different layers to 2 bytes
+    for a, b in zip(out[1][0], out[0][0]):
+        assert abs(a - b) < ltol, (tag, K, act, out[1][0], out[0][0])
+    for k in out[1][1]:
+        np.testing.assert_allclose(out[1][1][k], out[0][1][k], rtol=0, atol=ptol, err_msg=f"{tag} K={K} {act} {k}")
+    w.configure([])
+
+
 def test_checkpoint_resume_roundtrip(pkg, tiny, tmp_path):
     """Checkpoint surface of main.py:56-87: model.state_dict() (keys embedding_user/item.weight) +
     bpr.opt.state_dict() (torch-Adam format: step / exp_avg / exp_avg_sq) saved after 2 steps,
