@@ -68,6 +68,7 @@ SIGNATURES = {
     "lgcn_ctx_set_dp_local": (C.c_int, [_vp, C.c_int]),
     "lgcn_train_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_train_epoch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "lgcn_dp_block_floats": (C.c_int64, [_vp, C.c_int32, C.c_int32]),
     "lgcn_train_step_dp_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_dense_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),

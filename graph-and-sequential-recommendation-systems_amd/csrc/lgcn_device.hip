@@ -344,6 +344,7 @@ struct SpmmArgs {
     int clear;
     const float *terms; const float *gathered; float *loss_out; int32_t B, shard; float decay;
     float ent_coeff;              // popularity gate: coefficient of the gates' entropy term in the loss (0: no gate)
+    int64_t blk;                  // data parallel: floats per rank in `gathered` (0: the default layout 3*shard*D + 2*shard)
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
     const float *selfX;           // M_ADDSELF: Y[row] = selfX[row] + (A X)[row]  (item-item smoothing, model.py:228-229)
@@ -394,11 +395,13 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
 // deterministic reduction of the per-triplet loss / reg terms by ONE wave (fixed strided
 // partials, then an xor-shuffle tree): loss_out = {bpr + decay*reg, bpr, reg}   (model.py:168-173)
 __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float *gathered, int B, int shard,
-                                                 int D, float decay, float *loss_out, int lane, float ent_coeff = 0.f) {
+                                                 int D, float decay, float *loss_out, int lane, float ent_coeff = 0.f, int64_t blk_in = 0) {
     // Every lane adds its terms b = lane, lane + 64, ... in that order (the order is part of the result).
     float fl = 0.f, fr = 0.f, fe = 0.f;
-    if (ent_coeff != 0.f)          // popularity gate: entropy of the 2B gates, one sum per triplet at terms[2B + b] (model.py:176-181)
-        for (int b = lane; b < B; b += 64) fe += terms[2 * B + b];
+    if (ent_coeff != 0.f) {        // popularity gate: entropy of the 2B gates, one sum per triplet (model.py:176-181)
+        if (!gathered) { for (int b = lane; b < B; b += 64) fe += terms[2 * B + b]; }
+        else for (int b = lane; b < B; b += 64) fe += gathered[(int64_t)(b / shard) * blk_in + (int64_t)3 * shard * D + 2 * shard + b % shard];
+    }
     if (!gathered) {
         // one GPU: the plain loop (deeper explicit batches made the launch it rides in slower: 3214-3278 steps/s at
         // B = 8192 for 32 ... 4 loads in flight, 3296 for this form)
@@ -409,7 +412,7 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
         // round trip a 16 384-triplet batch (8 ranks) took 100 us and held the +Adam launch back (38 -> 108 us).
         // (r, i) = (block, position in it) of this lane's next term, advanced without divisions.
         constexpr int UL = 16;
-        const int64_t blk = (int64_t)3 * shard * D + 2 * shard;
+        const int64_t blk = blk_in ? blk_in : (int64_t)3 * shard * D + 2 * shard;
         int r = lane / shard, i = lane % shard;
         for (int b0 = 0; b0 < B; b0 += 64 * UL) {
             float tl[UL], tr[UL];
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
     //  sat on the tail and cost +25 us)
     if ((MODE & M_ADAM) && !SP && a.clear && blockIdx.x == 0 && wid == SPMM_WPB - 1)
-        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane, a.ent_coeff);
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, lane, a.ent_coeff, a.blk);
     int x, j;
     if (a.remap) { x = blockIdx.x & (XCDS - 1); j = blockIdx.x >> 3; }
     else {        // slices as contiguous block ranges (placement-independent either way: speed only)
@@ -1043,7 +1046,9 @@ struct GateArgs {
     const float *E;               // [N,d] final propagated table (layer mean, item-item smoothing applied)
     const float *item_pop;        // [m_items]
     const float *params;          // flat: W1[Hp] b1[Hp] W2[d*Hp] b2[d] V1[Hg*2d] c1[Hg] V2[Hg] c2[1]  (torch.nn.Linear layouts)
-    float *partials;              // [grid, P] per-workgroup parameter-gradient sums
+    long long *partials;          // [grid, P] per-workgroup parameter-gradient sums, FIXED POINT (2^50): every slot's contribution is
+                                  // converted before it is added, so the total is independent of how slots fall into workgroups and
+                                  // ranks (integer sums are associative) -- the data-parallel step equals the single-GPU step bit for bit
     int32_t Hp, Hg, P;
     float inv_temp, ent_scale;    // 1 / pop_gate_temp ; gate_entropy_coeff / (2 B)
     int32_t n_users; int64_t N;
@@ -1053,6 +1058,8 @@ struct GateArgs {
     uint32_t *stale_bitmap; int64_t bitmap_words;
     float *terms; int32_t terms_stride;
     int32_t *err;
+    float *contrib; int32_t shard; int32_t exchange;   // data parallel: gradient rows and loss terms of this rank's shard go to the exchange
+                                                        // block [3*shard*D | shard | shard | shard] (besides / instead of the atomics)
 };
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -1103,8 +1110,13 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
         if (b >= a.B) break;
         const int iu = a.users[b], ip = a.pos[b], in_ = a.neg[b];
         const bool bad = iu < 0 || iu >= a.n_users || ip < 0 || (int64_t)ip + a.n_users >= a.N || in_ < 0 || (int64_t)in_ + a.n_users >= a.N;
+        float *lt = a.exchange ? a.contrib + (int64_t)3 * a.shard * D : a.terms;
+        const int lts = a.exchange ? a.shard : a.terms_stride;
         if (bad) {
-            if (lane == 0) { atomicExch(a.err, 1); a.terms[b] = 0.f; a.terms[a.terms_stride + b] = 0.f; a.terms[2 * a.terms_stride + b] = 0.f; }
+            if (lane == 0) { atomicExch(a.err, 1); lt[b] = 0.f; lt[lts + b] = 0.f; lt[2 * lts + b] = 0.f; }
+            if (a.exchange && lane < LPT)
+                for (int c3 = 0; c3 < 3; c3++)
+                    for (int j = 0; j < CPT; j++) a.contrib[((int64_t)c3 * a.shard + b) * D + j * LPT + lane] = 0.f;
             continue;
         }
         const bool col = lane < LPT;
@@ -1160,19 +1172,18 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
         ps = wave_sum(ps); ns = wave_sum(ns); rr = wave_sum(rr);
         const float x = ps - ns;
         const float gb = -a.inv_B * sigmoid_neg_f(x);
-        if (lane == 0) {
-            a.terms[b] = logsigmoid_f(x); a.terms[a.terms_stride + b] = rr; a.terms[2 * a.terms_stride + b] = ent[0] + ent[1];
-        }
+        if (lane == 0) { lt[b] = logsigmoid_f(x); lt[lts + b] = rr; lt[2 * lts + b] = ent[0] + ent[1]; }
         // backward: user row
         const int64_t urow = iu;
 #pragma unroll
         for (int j = 0; j < CPT; j++) {
             if (col) {
                 const float du = gb * (f[0][j] - f[1][j]) + a.lam * u[j];
-                atomicAdd((unsigned long long *)(a.G64 + urow * D + j * LPT + lane), (unsigned long long)__double2ll_rn((double)du * FIXED_SCALE));
+                if (a.G64) atomicAdd((unsigned long long *)(a.G64 + urow * D + j * LPT + lane), (unsigned long long)__double2ll_rn((double)du * FIXED_SCALE));
+                if (a.exchange) a.contrib[((int64_t)0 * a.shard + b) * D + j * LPT + lane] = du;
             }
         }
-        if (lane == 0) atomicOr(a.bitmap + (urow >> 5), 1u << (urow & 31));
+        if (a.G64 && lane == 0) atomicOr(a.bitmap + (urow >> 5), 1u << (urow & 31));
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int sidx = 2 * tt + q;
@@ -1200,10 +1211,11 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
                 const float de = g[q] * dF[j] + die, dpv = (1.f - g[q]) * dF[j] + dip;
                 if (col) {
                     DPV[sidx * D + c] = dpv;
-                    atomicAdd((unsigned long long *)(a.G64 + row * D + c), (unsigned long long)__double2ll_rn((double)de * FIXED_SCALE));
+                    if (a.G64) atomicAdd((unsigned long long *)(a.G64 + row * D + c), (unsigned long long)__double2ll_rn((double)de * FIXED_SCALE));
+                    if (a.exchange) a.contrib[((int64_t)(1 + q) * a.shard + b) * D + c] = de;
                 }
             }
-            if (lane == 0) {
+            if (a.G64 && lane == 0) {
                 atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
                 if (a.item_bitmap) atomicOr(a.item_bitmap + (item[q] >> 5), 1u << (item[q] & 31));
             }
@@ -1217,18 +1229,19 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
         }
     }
     __syncthreads();
-    // ---- phase 2: this workgroup's parameter-gradient sums over its slots, slot order fixed
-    float *out = a.partials + (int64_t)blockIdx.x * a.P;
+    // ---- phase 2: this workgroup's parameter-gradient sums over its slots, every slot's term in fixed point
+    long long *out = a.partials + (int64_t)blockIdx.x * a.P;
+    auto fx = [](float v) { return __double2ll_rn((double)v * FIXED_SCALE); };
     for (int i = tid; i < a.P; i += 256) {
-        float v = 0.f;
-        if (i < Hp) { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + i] * SC[sI]; }
-        else if (i < oW2) { const int k = i - Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DA[sI * GATE_HMAX + k]; }
-        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c] * AA[sI * GATE_HMAX + k]; }
-        else if (i < oV1) { const int c = i - ob2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DPV[sI * D + c]; }
-        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]; }
-        else if (i < oV2) { const int jj = i - oc1; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DH[sI * GATE_HMAX + jj]; }
-        else if (i < oc2) { const int jj = i - oV2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI] * HR[sI * GATE_HMAX + jj]; }
-        else { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += DLOG[sI]; }
+        long long v = 0;
+        if (i < Hp) { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DA[sI * GATE_HMAX + i] * SC[sI]); }
+        else if (i < oW2) { const int k = i - Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DA[sI * GATE_HMAX + k]); }
+        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DPV[sI * D + c] * AA[sI * GATE_HMAX + k]); }
+        else if (i < oV1) { const int c = i - ob2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DPV[sI * D + c]); }
+        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]); }
+        else if (i < oV2) { const int jj = i - oc1; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DH[sI * GATE_HMAX + jj]); }
+        else if (i < oc2) { const int jj = i - oV2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DLOG[sI] * HR[sI * GATE_HMAX + jj]); }
+        else { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DLOG[sI]); }
         out[i] = v;
     }
 }
@@ -1238,26 +1251,26 @@ static size_t gate_lds_bytes(int D) {
     return fl * sizeof(float);
 }
 
-// sum of the workgroups' partial sums in index order + torch.optim.Adam on the MLP parameters (same arithmetic as
+// sum of the fixed-point partial sums (of the workgroups on one GPU; of the ranks' totals in the exchange blocks under data
+// parallelism -- integer sums: any grouping gives the same bits) + torch.optim.Adam on the MLP parameters (same arithmetic as
 // spmm_epilogue's); grad_out keeps the reduced gradient (tests, inspection)
 struct GateAdamArgs {
-    const float *partials; int32_t n_part, P;
+    const long long *src; int32_t n_src; int64_t stride; int32_t P;      // n_src vectors of P sums, `stride` int64 apart
     float *params, *m, *v, *grad_out;
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
 };
 __global__ void __launch_bounds__(256) k_gate_adam(GateAdamArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.P) return;
-    // the workgroups' partial sums in index order; 32 loads in flight per round trip (one load per round trip made this the
-    // longest launch of the gate step: 62 us for 256 partials)
-    float g = 0.f;
-    for (int q0 = 0; q0 < a.n_part; q0 += 32) {
-        float t[32];
+    long long q = 0;
+    for (int q0 = 0; q0 < a.n_src; q0 += 32) {               // 32 loads in flight per round trip
+        long long t[32];
 #pragma unroll
-        for (int u = 0; u < 32; u++) t[u] = q0 + u < a.n_part ? a.partials[(int64_t)(q0 + u) * a.P + i] : 0.f;
+        for (int u = 0; u < 32; u++) t[u] = q0 + u < a.n_src ? a.src[(int64_t)(q0 + u) * a.stride + i] : 0;
 #pragma unroll
-        for (int u = 0; u < 32; u++) g += t[u];
+        for (int u = 0; u < 32; u++) q += t[u];
     }
+    const float g = (float)((double)q * FIXED_INV);
     a.grad_out[i] = g;
     float m = a.m[i], v = a.v[i], p = a.params[i];
     m = m + a.w1 * (g - m);
@@ -1265,6 +1278,14 @@ __global__ void __launch_bounds__(256) k_gate_adam(GateAdamArgs a) {
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     p = p - a.step_size * (m / denom);
     a.params[i] = p; a.m[i] = m; a.v[i] = v;
+}
+// data parallel: this rank's total (sum of its workgroups' partial sums) into the tail of its exchange block
+__global__ void __launch_bounds__(256) k_gate_rank_total(const long long *partials, int32_t n_part, int32_t P, long long *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    long long q = 0;
+    for (int w = 0; w < n_part; w++) q += partials[(int64_t)w * P + i];
+    out[i] = q;
 }
 
 // T = mean of the K+1 layers (the stack + mean of computer(), model.py:221-222): user rows to out_u, item rows to out_i
@@ -1310,6 +1331,8 @@ struct SlotArgs {
     int32_t skip_rank;                                     // DP scatter: this rank's own block is in G64 already (-1: none)
     const float *terms; float *loss_out; float decay;
     float ent_coeff;
+    int64_t blk;                                           // floats per rank in `gathered` (0: default layout)
+    uint32_t *item_bitmap;                                 // DP scatter with item-item smoothing: items named by the global batch
 };
 
 // DP: order-independent scatter of every rank's gradient rows into G64 (+ row flags)
@@ -1326,13 +1349,16 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
     if (row < 0) return;
     const int r = b / a.shard, i = b % a.shard;
     if (r == a.skip_rank) return;
-    const int64_t blk = (int64_t)3 * a.shard * D + 2 * a.shard;
+    const int64_t blk = a.blk ? a.blk : (int64_t)3 * a.shard * D + 2 * a.shard;
     const float *src = a.gathered + r * blk + ((int64_t)c * a.shard + i) * D;
 #pragma unroll
     for (int j = 0; j < CPT; j++)
         atomicAdd((unsigned long long *)(a.G64 + row * D + j * LPT + l),
                   (unsigned long long)__double2ll_rn((double)src[j * LPT + l] * FIXED_SCALE));
-    if (l == 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+    if (l == 0) {
+        atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+        if (a.item_bitmap && c > 0) { const int64_t it = row - a.n_users; atomicOr(a.item_bitmap + (it >> 5), 1u << (it & 31)); }
+    }
 }
 
 // Gs rows of the batch, once per step: G32[row] = (float)(G64[row] * 2^-50) / (K+1) for every slot's row, after
@@ -1375,7 +1401,7 @@ __global__ void __launch_bounds__(256) k_finish(SlotArgs a) {
     }
     // the same single-wave, fixed-order reduction as the fused finish of the last SpMM: identical bits
     if (blockIdx.x == 0 && threadIdx.x < 64)
-        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, (int)threadIdx.x, a.ent_coeff);
+        reduce_loss_wave(a.terms, a.gathered, a.B, a.shard, D, a.decay, a.loss_out, (int)threadIdx.x, a.ent_coeff, a.blk);
 }
 
 __global__ void __launch_bounds__(256) k_apply_perm(const int32_t *S, int cols, const int64_t *perm, int64_t T,
@@ -1781,7 +1807,7 @@ struct lgcn_ctx {
     bool variant;                 // either branch is on
     float *tvar;                  // [N,d] fp32 final propagated table T (library-owned)
     uint32_t *item_bitmap;        // [ceil(m_items/32)] items named by the batch (item-item backward), library-owned
-    float *gate_partials;         // [n_wg, P] parameter-gradient partial sums (library-owned)
+    long long *gate_partials;     // [n_wg, P] parameter-gradient partial sums, fixed point (library-owned)
     int32_t gate_P, gate_wgs;
 };
 // a multi-step call: nobody but this library touches E0 between its steps
@@ -1834,7 +1860,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (ok && gate) {
         x->gate_P = 2 * c.pop_hidden + c.d * c.pop_hidden + c.d + 2 * c.d * c.gate_hidden + 2 * c.gate_hidden + 1;
         x->gate_wgs = (c.max_batch + GATE_TPB - 1) / GATE_TPB;
-        ok = hipMalloc((void **)&x->gate_partials, sizeof(float) * (size_t)x->gate_wgs * x->gate_P) == hipSuccess;
+        ok = hipMalloc((void **)&x->gate_partials, sizeof(long long) * (size_t)x->gate_wgs * x->gate_P) == hipSuccess;
     }
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
     if (ok && !c.dense_last) {
@@ -1965,9 +1991,27 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     return 0;
 }
 
+// floats per rank of the data-parallel exchange block for a shard of S triplets: [3*S*d gradient rows | S loss | S reg terms], with
+// the popularity gate also [S entropy terms | pad to an even count | 2*P floats = P int64: the rank's fixed-point MLP gradient sums]
+static int64_t dp_block_floats(const lgcn_ctx *x, int64_t S) {
+    int64_t n = 3 * S * x->c.d + 2 * S;
+    if (x->variant && x->c.item_pop) { n += S; n += n & 1; n += 2 * (int64_t)x->gate_P; }
+    return n;
+}
+static int64_t dp_block_tail(const lgcn_ctx *x, int64_t S) {          // float offset of the int64 tail inside a block
+    int64_t n = 3 * S * x->c.d + 3 * S;
+    return n + (n & 1);
+}
+extern "C" int64_t lgcn_dp_block_floats(const lgcn_ctx *x, int32_t B_global, int32_t world) {
+    if (!x || B_global <= 0 || world < 1) return 0;
+    return dp_block_floats(x, (B_global + world - 1) / world);
+}
+
 // The optional branches' forward tail and loss: T = mean of the K+1 dense layers, item-item smoothing, then the loss on the
-// ONE final table (popularity gate inside k_triplet_gate).  Single GPU, whole batch.
-static int run_variant_loss(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B, hipStream_t st) {
+// ONE final table (popularity gate inside k_triplet_gate).  The batch slice [b_off, b_off + B_local) of a global batch of
+// B_global triplets (single GPU: the whole batch); atomics: into G64 / the row flags; exchange: into the exchange block.
+static int run_variant_loss(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B_global,
+                            int32_t b_off, int32_t B_local, int32_t shard, bool atomics, bool exchange, hipStream_t st) {
     const lgcn_train_config &c = x->c;
     const int64_t m_items = x->N - c.n_users;
     float *items_mean = c.i2i ? x->g32 : x->tvar;           // with smoothing the item block of T is an SpMM input first
@@ -1990,16 +2034,23 @@ static int run_variant_loss(lgcn_ctx *x, const int32_t *users, const int32_t *po
         HIP_OK(hipMemsetAsync(x->item_bitmap, 0, sizeof(uint32_t) * (size_t)((m_items + 31) / 32), st));
     }
     uint32_t *bm = c.bitmap + x->flip * x->bm_words, *stale = c.bitmap + (x->flip ^ 1) * x->bm_words;
+    const int64_t tail = dp_block_tail(x, shard);
+    if (B_local <= 0) {     // an empty shard: nothing to launch, but the stale bitmap must go and the block's MLP sums must read zero
+        HIP_OK(hipMemsetAsync(stale, 0, sizeof(uint32_t) * (size_t)x->bm_words, st));
+        if (exchange && c.item_pop) HIP_OK(hipMemsetAsync(c.contrib + tail, 0, sizeof(long long) * (size_t)x->gate_P, st));
+        return 0;
+    }
     if (c.item_pop) {
         GateArgs g{};
         g.E = x->tvar; g.item_pop = c.item_pop; g.params = c.gate_params; g.partials = x->gate_partials;
         g.Hp = c.pop_hidden; g.Hg = c.gate_hidden; g.P = x->gate_P;
-        g.inv_temp = 1.0f / c.pop_gate_temp; g.ent_scale = c.gate_entropy_coeff / (float)(2 * B);
-        g.n_users = c.n_users; g.N = x->N; g.users = users; g.pos = pos; g.neg = neg; g.B = B;
-        g.inv_B = 1.0f / (float)B; g.lam = c.decay / (float)B;
-        g.G64 = (long long *)c.G64; g.bitmap = bm; g.item_bitmap = c.i2i ? x->item_bitmap : nullptr;
-        g.stale_bitmap = stale; g.bitmap_words = x->bm_words; g.terms = c.terms; g.terms_stride = B; g.err = c.err;
-        const unsigned grid = (unsigned)((B + GATE_TPB - 1) / GATE_TPB);
+        g.inv_temp = 1.0f / c.pop_gate_temp; g.ent_scale = c.gate_entropy_coeff / (float)(2 * B_global);
+        g.n_users = c.n_users; g.N = x->N; g.users = users + b_off; g.pos = pos + b_off; g.neg = neg + b_off; g.B = B_local;
+        g.inv_B = 1.0f / (float)B_global; g.lam = c.decay / (float)B_global;
+        g.G64 = atomics ? (long long *)c.G64 : nullptr; g.bitmap = bm; g.item_bitmap = c.i2i ? x->item_bitmap : nullptr;
+        g.stale_bitmap = stale; g.bitmap_words = x->bm_words; g.terms = c.terms + (exchange ? 0 : b_off); g.terms_stride = B_global; g.err = c.err;
+        g.contrib = c.contrib; g.shard = shard; g.exchange = exchange ? 1 : 0;
+        const unsigned grid = (unsigned)((B_local + GATE_TPB - 1) / GATE_TPB);
         const size_t lds = gate_lds_bytes(c.d);
         switch (c.d) {
         case 32: HIP_OK(hipFuncSetAttribute((const void *)k_triplet_gate<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2010,16 +2061,20 @@ static int run_variant_loss(lgcn_ctx *x, const int32_t *users, const int32_t *po
                  hipLaunchKernelGGL((k_triplet_gate<128>), dim3(grid), dim3(256), lds, st, g); break;
         default: lgcn_set_error("popularity gate: embedding dim must be 32, 64 or 128"); return 3;
         }
+        if (exchange)       // this rank's MLP gradient sums into the tail of its exchange block
+            hipLaunchKernelGGL(k_gate_rank_total, dim3((unsigned)((x->gate_P + 255) / 256)), dim3(256), 0, st,
+                               (const long long *)x->gate_partials, (int32_t)grid, x->gate_P, (long long *)(c.contrib + tail));
     } else {
         BprArgs a{};
         a.X0 = x->tvar; a.K = 0; a.dense_last = 1;            // e = the row of the final table
-        a.n_users = c.n_users; a.N = x->N; a.users = users; a.pos = pos; a.neg = neg; a.B_local = B; a.shard = B;
-        a.inv_B = 1.0f / (float)B; a.lam = c.decay / (float)B;
-        a.G64 = (long long *)c.G64; a.bitmap = bm; a.stale_bitmap = stale; a.bitmap_words = x->bm_words;
-        a.item_bitmap = x->item_bitmap; a.terms = c.terms; a.err = c.err; a.terms_off = 0; a.terms_stride = B;
+        a.n_users = c.n_users; a.N = x->N; a.users = users + b_off; a.pos = pos + b_off; a.neg = neg + b_off; a.B_local = B_local; a.shard = shard;
+        a.inv_B = 1.0f / (float)B_global; a.lam = c.decay / (float)B_global;
+        a.G64 = atomics ? (long long *)c.G64 : nullptr; a.bitmap = bm; a.stale_bitmap = stale; a.bitmap_words = x->bm_words;
+        a.item_bitmap = x->item_bitmap; a.terms = c.terms; a.err = c.err; a.terms_off = exchange ? 0 : b_off; a.terms_stride = B_global;
+        a.contrib = c.contrib; a.exchange = exchange ? 1 : 0;
         DISPATCH_D(c.d, {
             const int tpb = 256 / (D < 64 ? D : 64);
-            hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3((unsigned)((B + tpb - 1) / tpb)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3((unsigned)((B_local + tpb - 1) / tpb)), dim3(256), 0, st, a);
         });
     }
     return 0;
@@ -2034,6 +2089,8 @@ static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t
     s.bitmap = c.bitmap + x->flip * x->bm_words; s.gathered = gathered; s.shard = shard; s.world = world;
     s.terms = c.terms; s.loss_out = loss_out; s.decay = c.decay; s.skip_rank = -1;
     s.ent_coeff = c.item_pop ? c.gate_entropy_coeff : 0.f;
+    s.blk = gathered ? dp_block_floats(x, shard) : 0;
+    s.item_bitmap = (x->variant && c.i2i) ? x->item_bitmap : nullptr;
     return s;
 }
 static unsigned scatter_grid(const lgcn_ctx *x, int32_t B) {      // k_scatter: one lane group of min(d, 64) lanes per slot
@@ -2092,6 +2149,7 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
         if (!first && fused_finish) {       // K >= 2: this launch also cleans the workspace and reduces the loss
             a.clear = 1; a.terms = c.terms; a.gathered = gathered; a.loss_out = loss_out;
             a.B = B; a.shard = shard; a.decay = c.decay; a.ent_coeff = c.item_pop ? c.gate_entropy_coeff : 0.f;
+            a.blk = gathered ? dp_block_floats(x, shard) : 0;
         }
     }
     const int prev_dt = first ? LGCN_F32 : c.act_dtype;
@@ -2120,7 +2178,10 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
     }
     if (x->variant && c.item_pop) {          // torch.optim.Adam on the gate's MLP parameters, same step count as the tables
         GateAdamArgs ga{};
-        ga.partials = x->gate_partials; ga.n_part = (B + GATE_TPB - 1) / GATE_TPB; ga.P = x->gate_P;
+        if (gathered) {      // data parallel: the ranks' totals sit in the tails of their exchange blocks
+            ga.src = (const long long *)(gathered + dp_block_tail(x, shard)); ga.n_src = world; ga.stride = dp_block_floats(x, shard) / 2;
+        } else { ga.src = x->gate_partials; ga.n_src = (B + GATE_TPB - 1) / GATE_TPB; ga.stride = x->gate_P; }
+        ga.P = x->gate_P;
         ga.params = c.gate_params; ga.m = c.gate_adam_m; ga.v = c.gate_adam_v; ga.grad_out = c.gate_grad;
         const double bc1 = 1.0 - pow(c.beta1, (double)x->step), bc2 = 1.0 - pow(c.beta2, (double)x->step);
         ga.step_size = (float)(c.lr / bc1); ga.bc2_sqrt = (float)sqrt(bc2);
@@ -2150,7 +2211,7 @@ extern "C" int lgcn_train_step(lgcn_ctx *x, const int32_t *users, const int32_t 
     if (!loss_out) { lgcn_set_error("train step: loss_out is null"); return 3; }
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_forward(x, st))) return rc;
-    if (x->variant) rc = run_variant_loss(x, users, pos, neg, B, st);
+    if (x->variant) rc = run_variant_loss(x, users, pos, neg, B, 0, B, B, true, false, st);
     else rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, false, st);
     if (rc) return rc;
     if ((rc = run_backward(x, users, pos, neg, B, nullptr, B, 1, loss_out, st))) return rc;
@@ -2177,7 +2238,6 @@ extern "C" int lgcn_train_step_dp_part1(lgcn_ctx *x, const int32_t *users, const
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
     if (!x->c.contrib) { lgcn_set_error("dp step: cfg.contrib exchange buffer missing"); return 3; }
-    if (x->variant) { lgcn_set_error("dp step: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("dp step: bad world/rank"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
     const int32_t b_off = rank * shard;
@@ -2187,7 +2247,9 @@ extern "C" int lgcn_train_step_dp_part1(lgcn_ctx *x, const int32_t *users, const
     hipStream_t st = (hipStream_t)stream;
     if ((rc = run_forward(x, st))) return rc;
     // with dp_local the rank's own rows go into G64 here (atomics) AND into the exchange block; part 2 scatters the others'
-    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, x->dp_local, true, st))) return rc;
+    if (x->variant) rc = run_variant_loss(x, users, pos, neg, B_global, b_off, B_local, shard, x->dp_local, true, st);
+    else rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, x->dp_local, true, st);
+    if (rc) return rc;
     x->dp_rank = rank;
     HIP_OK(hipGetLastError());
     return 0;
@@ -2362,7 +2424,7 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
             if ((rc = lgcn_rs_phase(x, LGCN_RS_FINISH, 0, u, p, n, b, world, rank, gathered, loss_out + 3 * i, stream))) return rc;
         } else if (reduce == LGCN_DP_ROWS) {
             if ((rc = lgcn_train_step_dp_part1(x, users + t, pos + t, neg + t, b, world, rank, stream))) return rc;
-            const int64_t S = (b + world - 1) / world, blk = 3 * S * x->c.d + 2 * S;
+            const int64_t S = (b + world - 1) / world, blk = dp_block_floats(x, S);
             r = api->AllGather(x->c.contrib, gathered, (size_t)blk, ncclFloat32, dp->comm, st);
             if (r != ncclSuccess) { lgcn_set_error("ncclAllGather failed"); return 11; }
             if ((rc = lgcn_train_step_dp_part2(x, users + t, pos + t, neg + t, b, world, gathered, loss_out + 3 * i, stream))) return rc;

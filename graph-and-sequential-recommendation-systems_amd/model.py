@@ -302,7 +302,9 @@ class LightGCN(nn.Module):
         st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
         st['terms'] = torch.zeros(3 * max_batch, dtype=torch.float32, device=dev)
         shard = (max_batch + dp_world - 1) // dp_world
-        st['contrib'] = torch.zeros(3 * shard * d + 2 * shard, dtype=torch.float32, device=dev)
+        gate_p = sum(prm.numel() for prm in self.gate_parameters()) if (variants and self.use_pop_gate) else 0
+        # exchange block of a rank (lgcn_dp_block_floats): gradient rows, loss / reg (/ entropy) terms, the gate's fixed-point MLP sums
+        st['contrib'] = torch.zeros(3 * shard * d + 3 * shard + 2 + 2 * gate_p, dtype=torch.float32, device=dev)
         st['err'] = torch.zeros(1, dtype=torch.int32, device=dev)
         cfg = _lib.TrainConfig()
         rows = rows or st.get('ctx_rows', 'all')

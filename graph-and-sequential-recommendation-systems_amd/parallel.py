@@ -97,8 +97,9 @@ class DataParallelBPR:
         from .utils import _AdamView
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        if getattr(recmodel, 'has_variants', False):
-            raise NotImplementedError("data-parallel training covers the default model (no popularity gate / item-item smoothing)")
+        if getattr(recmodel, 'has_variants', False) and not (getattr(recmodel, 'fused_variants', False) and reduce == 'rows' and shard == 'batch'):
+            raise NotImplementedError("with the popularity gate / item-item smoothing, data-parallel training needs the fused step "
+                                      "(--fused_variants 1) and the gradient-row exchange: reduce='rows', shard='batch'")
         self.model = recmodel
         self.group = group
         self.world = dist.get_world_size(group)
@@ -218,7 +219,7 @@ class DataParallelBPR:
         lib.lgcn_ctx_set_lr(st['ctx'], float(self.opt.param_groups[0]['lr']))
         steps = (T + global_batch - 1) // global_batch
         losses = torch.empty(steps, 3, dtype=torch.float32, device=dev)
-        n = self.world * block_numel(global_batch, self.world, m.latent_dim)
+        n = self.world * int(lib.lgcn_dp_block_floats(st['ctx'], int(global_batch), self.world))
         if self.reduce == 'rows' and (self._gathered is None or self._gathered.numel() < n):
             self._gathered = torch.empty(n, dtype=torch.float32, device=dev)
         mode = 2 if self.shard == 'rows' else (0 if self.reduce == 'rows' else 1)
@@ -246,7 +247,7 @@ class DataParallelBPR:
         if self.reduce == 'rows':
             _lib.check(lib.lgcn_train_step_dp_part1(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
                                                     self.world, self.rank, stream), "lgcn_train_step_dp_part1")
-            n = block_numel(B, self.world, m.latent_dim)
+            n = int(lib.lgcn_dp_block_floats(st['ctx'], B, self.world))
             gathered = exchange(st['contrib'][:n], self.group)
             gptr = _lib.tp(gathered)
         else:       # literal form: all-reduce of the (fixed-point) gradient table -- N*d*8 bytes per step

@@ -235,6 +235,12 @@ int lgcn_train_epoch(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, co
  *   (caller: RCCL all-gather of that block over the ranks into `gathered`)
  *   part 2  order-independent reduction of all ranks' rows, backward propagation
  *           and Adam -- bitwise identical on every rank and to lgcn_train_step.  */
+/* Floats per rank of the exchange block for a global batch of B_global triplets over `world` ranks (S = ceil(B_global/world)):
+ * 3*S*d + 2*S for the default model; with the popularity gate 3*S*d + 3*S (third term block: the gates' entropy), padded to
+ * an even count, + 2*P floats holding P int64 = the rank's fixed-point sums of the MLP parameter gradients.  cfg.contrib must
+ * hold that many floats for the largest batch, `gathered` world times as many.  The optional branches are supported in the
+ * gradient-row exchange (LGCN_DP_ROWS) only.                                                                      */
+int64_t lgcn_dp_block_floats(const lgcn_ctx *ctx, int32_t B_global, int32_t world);
 int lgcn_train_step_dp_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
                              const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
                              void *stream);

@@ -379,6 +379,87 @@ def test_dp_epoch_c_loop_world_gt_1_loopback(pkg, tiny, lastfm, tmp_path, world,
         lib.lgcn_dp_destroy(comms[r])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
+def test_dp_epoch_optional_branches_loopback(pkg, tiny, tmp_path, tag, world):
+    """The popularity gate / item-item smoothing under data parallelism (gradient-row exchange): W threads, each with its own model
+    (own MLP parameter buffer, own item-item graphs), context, stream and loopback communicator run lgcn_train_epoch_dp; the exchange
+    block carries the gradient rows, the loss / reg / ENTROPY terms and the rank's fixed-point sums of the MLP parameter gradients.
+    Ragged shards (the batch is not a multiple of the world, nor the shard of the 8 triplets a gate workgroup handles) and an empty
+    trailing rank in the last batch: every rank's tables, MLP parameters and per-step losses end bit for bit where the single-GPU
+    fused epoch ends."""
+    import threading
+    meta = json.load(open(os.path.join(tiny.dir, f"golden_{tag}.json")))
+    d = os.path.join(str(tmp_path), "tiny_dp_" + tag)
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(tiny.dir, f), os.path.join(d, f))
+    w = pkg.world
+    w.configure([])
+    w.dataset = "tiny"
+    B = 44
+    w.config.update({'lightGCN_n_layers': meta["K"], 'latent_dim_rec': meta["d"], 'bpr_batch_size': B, 'decay': meta["decay"], 'lr': meta["lr"],
+                     'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"],
+                     'i2i_path': os.path.join(tiny.dir, "i2i_tiny.npz") if meta["use_item_item"] else None, 'i2i_alpha': meta["i2i_alpha"],
+                     'fused_variants': 1})
+    w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
+    ds = pkg.dataloader.Loader(w.config, path=d)
+
+    def fresh():
+        pkg.utils.set_seed(meta["seed"])
+        m = pkg.model.LightGCN(w.config, ds).to(DEV)
+        m.train()
+        return m
+    rng = np.random.Generator(np.random.PCG64(3 * world + len(tag)))
+    T = 3 * B + 1                                              # last global batch: one triplet -> trailing ranks get none
+    u = rng.integers(0, ds.n_users, T); p = rng.integers(0, ds.m_items, T); n = rng.integers(0, ds.m_items, T)
+    p[:5] = p[5]; n[9] = p[5]; u[20] = u[30]
+    U, P, Nn = (_dev(x, torch.int32) for x in (u, p, n))
+    ref = fresh()
+    want_loss = ref.fused_epoch(U, P, Nn, B).cpu().numpy()
+    want = {k: v.detach().cpu().numpy().copy() for k, v in ref.state_dict().items()}
+    L, lib = pkg._lib, pkg._lib.load()
+    models = [fresh() for _ in range(world)]
+    states = [m._state(max_batch=B, need_ctx=True, dp_world=world) for m in models]
+    comms = (C.c_void_p * world)()
+    L.check(lib.lgcn_dp_init_loopback(world, comms), "loopback")
+    steps = (T + B - 1) // B
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    nblk = int(lib.lgcn_dp_block_floats(states[0]['ctx'], B, world))
+    assert nblk > pkg.parallel.block_numel(B, world, meta["d"]) or not meta["use_pop_gate"]
+    gathered = [torch.empty(world * nblk, device=DEV) for _ in range(world)]
+    losses = [torch.empty(steps, 3, device=DEV) for _ in range(world)]
+    torch.cuda.synchronize()
+    rcs, errs = [None] * world, [None] * world
+
+    def rank_main(r):
+        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, 0, None, L.tp(gathered[r]),
+                                         L.tp(losses[r]), C.c_void_p(streams[r].cuda_stream))
+        if rcs[r]:
+            errs[r] = lib.lgcn_last_error()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads)
+    torch.cuda.synchronize()
+    assert rcs == [0] * world, (rcs, errs)
+    for r, m in enumerate(models):
+        assert np.array_equal(losses[r].cpu().numpy(), want_loss), (tag, world, r, losses[r].cpu().numpy(), want_loss)
+        for k, v in m.state_dict().items():
+            assert np.array_equal(v.detach().cpu().numpy().view(np.uint32), want[k].view(np.uint32)), (tag, world, r, k)
+        assert not bool(m._dev['G64'].any())
+        m.check_device_errors()
+    for r in range(world):
+        lib.lgcn_dp_destroy(comms[r])
+    # dense all-reduce and row-sharded propagation refuse a context with a branch on
+    st = models[0]._dev
+    rc = lib.lgcn_train_step_dp_dense_part1(st['ctx'], L.tp(U), L.tp(P), L.tp(Nn), B, world, 0, L.current_stream())
+    assert rc != 0
+    w.configure([])
+
+
 def test_out_of_range_ids_are_flagged_not_faulting(pkg, tiny, tmp_path):
     ds, m = _make_model(pkg, tiny, tmp_path)
     before = m._table.clone()
