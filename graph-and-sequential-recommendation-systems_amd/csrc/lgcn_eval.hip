@@ -35,8 +35,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define EVAL_KMAX 32
 #define EVAL_NEG_INF (-3.0e38f)
 #ifndef EVAL_PARTS
-#define EVAL_PARTS 2          /* workgroups per user block (<= 4) when two fit a CU */
+#define EVAL_PARTS 3          /* workgroups per user block (<= 4) = workgroups that fit a CU with the compact lists */
 #endif
+// Ids in the per-lane lists: int32 item ids, or (compact form) 16-bit offsets from the first item of the workgroup's
+// part of the sweep -- 10 KB less LDS per workgroup, which is what lets a third workgroup share the CU.
+template <typename IDT> struct ListId;
+template <> struct ListId<int32_t> { static constexpr int32_t EMPTY = -1; static constexpr int PAD = 1; };
+template <> struct ListId<uint16_t> { static constexpr uint16_t EMPTY = 0xffffu; static constexpr int PAD = 0; };
+#define EVAL_ID16_MAX_TILES 2047        /* 2047 * 32 + 31 < 0xffff */
 
 struct EvalArgs {
     const float *E; int32_t n_users, m_items;
@@ -49,16 +55,17 @@ struct EvalArgs {
     int32_t *part_items; float *part_scores;      // [n_eval, gridDim.y, K] or NULL (gridDim.y == 1: straight to out_*)
 };
 
-template <int D, int KS>        // KS: list slots per lane (a multiple of 4, >= K)
-__global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
+template <int D, int KS, typename IDT, int WGS>        // KS: list slots per lane (a multiple of 4, >= K); WGS: workgroups per CU
+__global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     constexpr int HALF = D / 2, RS = D + 4;            // row stride of the LDS item tile (floats)
     constexpr int LPT = 32 * D * 4 / 16 / 256;          // 16-byte pieces per thread per item tile
     static_assert(LPT >= 1, "tile smaller than the workgroup");
     __shared__ __attribute__((aligned(16))) float tile_lds[2][32 * RS];
     // per-lane candidate lists: KS slots (slots >= K hold +inf: never the minimum, never output),
     // 16-byte aligned rows so the minimum scan is KS/4 independent ds_read_b128
-    __shared__ __attribute__((aligned(16))) float list_s[256][KS + 4];
-    __shared__ int32_t list_i[256][KS + 1];
+    // (row stride KS floats = 80 / 128 bytes: 16 lanes' 16-byte reads start 20 / 32 banks apart and cover the 64 banks once)
+    __shared__ __attribute__((aligned(16))) float list_s[256][KS];
+    __shared__ IDT list_i[256][KS + ListId<IDT>::PAD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int K = a.K;
@@ -92,7 +99,8 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
         if (tp < tend) nid = a.train_idx[tp];
         if (tp + 1 < tend) nnid = a.train_idx[tp + 1];
     }
-    for (int k = 0; k < KS; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = -1; }
+    for (int k = 0; k < KS; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = ListId<IDT>::EMPTY; }
+    const int id0 = sizeof(IDT) == 2 ? t_begin * 32 : 0;       // list ids are stored relative to this
     float thr = EVAL_NEG_INF;      // the lane's K-th best so far
     int pmin = 0;                  // where it sits in the list
 
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
                 for (int r = 1; r < 16; r++) sc = reg == r ? acc[r] : sc;
                 if (sc > thr) {                                         // thr may have risen since the marking
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    list_s[tid][pmin] = sc; list_i[tid][pmin] = base + row;
+                    list_s[tid][pmin] = sc; list_i[tid][pmin] = (IDT)(base + row - id0);
                     // new minimum: all slots read at once (no dependent LDS round trips), then a register scan
                     f32x4 q[KS / 4];
 #pragma unroll
@@ -189,11 +197,12 @@ __global__ void __launch_bounds__(256, 1) k_eval_topk(EvalArgs a) {
             for (int w = 0; w < 2; w++) {
                 const int src = w ? other : tid;
                 for (int k = 0; k < K; k++) {
-                    const float v = list_s[src][k]; const int id = list_i[src][k];
-                    if (id >= 0 && (v > best || (v == best && id < bi))) { best = v; bi = id; bw = src; bk = k; }
+                    const float v = list_s[src][k]; const IDT raw = list_i[src][k];
+                    const int id = id0 + (int)raw;
+                    if (raw != ListId<IDT>::EMPTY && (v > best || (v == best && id < bi))) { best = v; bi = id; bw = src; bk = k; }
                 }
             }
-            if (bw >= 0) list_i[bw][bk] = -1;                  // taken
+            if (bw >= 0) list_i[bw][bk] = ListId<IDT>::EMPTY;  // taken
             if (a.part_items) {
                 const int64_t o = (slot * gridDim.y + blockIdx.y) * K + r;
                 a.part_items[o] = bw >= 0 ? bi : -1; a.part_scores[o] = best;
@@ -290,9 +299,14 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr};
     const unsigned blocks = (unsigned)((n_eval + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    // two workgroups per user block when two of them fit a CU (LDS: d <= 64 with 20 list slots) and the sweep is long
-    // (measured on Gowalla: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
-    const int parts = (d <= 64 && K <= 20 && m_items >= 4096) ? EVAL_PARTS : 1;
+    // The item sweep is split over `parts` workgroups per user block, as many as fit a CU together, so that one's list
+    // maintenance runs under the others' MFMAs.  Compact lists (16-bit ids relative to the part's first item: d <= 64,
+    // K <= 20, at most 2047 tiles per part) make that three; otherwise two (d <= 64, K <= 20) or one.
+    // (measured on Gowalla with int32 ids, two per CU: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
+    const int ntiles = (m_items + 31) / 32;
+    const bool split = d <= 64 && K <= 20 && m_items >= 4096;
+    const bool id16 = split && (ntiles + EVAL_PARTS - 1) / EVAL_PARTS + 1 <= EVAL_ID16_MAX_TILES;
+    const int parts = id16 ? EVAL_PARTS : split ? 2 : 1;
     void *tmp = nullptr;
     bool tmp_sync = false;
     if (parts > 1) {
@@ -306,15 +320,18 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
         a.part_items = (int32_t *)tmp; a.part_scores = (float *)((int32_t *)tmp + n);
     }
     const dim3 grid(blocks, parts);
-#define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20>), grid, dim3(256), 0, st, a); \
-                            else hipLaunchKernelGGL((k_eval_topk<DD, 32>), grid, dim3(256), 0, st, a); } while (0)
+#define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20, int32_t, 1>), grid, dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((k_eval_topk<DD, 32, int32_t, 1>), grid, dim3(256), 0, st, a); } while (0)
+#define EVAL_LAUNCH_SMALL(DD) do { if (id16) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS>), grid, dim3(256), 0, st, a); \
+                                  else EVAL_LAUNCH(DD); } while (0)
     switch (d) {
-    case 32: EVAL_LAUNCH(32); break;
-    case 64: EVAL_LAUNCH(64); break;
+    case 32: EVAL_LAUNCH_SMALL(32); break;
+    case 64: EVAL_LAUNCH_SMALL(64); break;
     case 128: EVAL_LAUNCH(128); break;
     case 256: EVAL_LAUNCH(256); break;
     default: if (tmp) { if (tmp_sync) (void)hipFree(tmp); else (void)hipFreeAsync(tmp, st); } lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
     }
+#undef EVAL_LAUNCH_SMALL
 #undef EVAL_LAUNCH
     if (parts > 1) {
         hipLaunchKernelGGL(k_eval_merge, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, st, a, parts);

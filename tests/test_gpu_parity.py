@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, assert_rows_close, spmm_sum_bound
+from conftest import EPS32, GOLDEN, assert_rows_close, spmm_sum_bound
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -1050,6 +1050,63 @@ def test_dp_empty_trailing_shard(pkg, tiny, tmp_path):
         assert np.array_equal(m._table.cpu().numpy().view(np.uint32), ref._table.cpu().numpy().view(np.uint32))
         assert torch.equal(m._dev['bitmap'], ranks[0]._dev['bitmap'])
         assert int(m._dev['G64'].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("m_items,d,K,n_eval", [(5000, 64, 20, 300), (4100, 32, 7, 130), (200000, 64, 20, 160), (9000, 64, 25, 129),
+                                                (6000, 128, 20, 200)])
+def test_eval_topk_every_sweep_form_vs_torch(pkg, m_items, d, K, n_eval):
+    """lgcn_eval_topk on synthetic tables, one case per form of the item sweep: three workgroups per user block with compact
+    lists (16-bit ids relative to the part's first item; d <= 64, K <= 20), two with int32 ids (parts too long for 16 bits),
+    one (K > 20 or d > 64).  Train positives clustered inside single 32-item tiles, at the part boundaries and at the table's
+    end; an unsorted, repeating user list.  Against torch matmul + mask + topk: same ids in the same order except where two
+    scores tie within fp32 rounding, masked items never returned."""
+    L, lib = pkg._lib, pkg._lib.load()
+    rng = np.random.Generator(np.random.PCG64(m_items + d + K))
+    n_users = 400
+    E = torch.from_numpy(rng.standard_normal((n_users + m_items, d)).astype(np.float32)).to(DEV)
+    users = rng.integers(0, n_users, n_eval).astype(np.int32)
+    ntiles = (m_items + 31) // 32
+    rows = []
+    for u in range(n_users):
+        c = set(rng.integers(0, m_items, rng.integers(0, 40)).tolist())
+        t0 = int(rng.integers(0, ntiles - 1)) * 32
+        c |= set(range(t0 + int(rng.integers(0, 8)), min(m_items, t0 + 32 + int(rng.integers(0, 20)))))      # a cluster across a tile edge
+        for parts in (2, 3):
+            b = (ntiles * (u % parts) // parts) * 32                                                     # around a part boundary
+            c |= {min(m_items - 1, max(0, b - 1)), min(m_items - 1, b), min(m_items - 1, b + 1)}
+        if u % 7 == 0:
+            c |= {m_items - 1, m_items - 2}
+        if u % 11 == 0:
+            c = set()
+        rows.append(np.array(sorted(c), np.int32))
+    ptr = np.zeros(n_users + 1, np.int64); ptr[1:] = np.cumsum([len(r) for r in rows])
+    idx = np.concatenate(rows).astype(np.int32)
+    topk = torch.full((n_eval, K), -7, dtype=torch.int32, device=DEV)
+    sc = torch.empty(n_eval, K, dtype=torch.float32, device=DEV)
+    d_users, d_ptr, d_idx = _dev(users), _dev(ptr), _dev(idx)        # (named: a temporary's memory is reused by the next allocation)
+    assert d_users.dtype == torch.int32 and d_ptr.dtype == torch.int64 and d_idx.dtype == torch.int32
+    assert int(d_users.max()) < n_users and int(d_ptr[-1]) == d_idx.numel() and int(d_idx.max()) < m_items and E.shape == (n_users + m_items, d)
+    L.check(lib.lgcn_eval_topk(L.tp(E), n_users, m_items, d, L.tp(d_users), n_eval, L.tp(d_ptr), L.tp(d_idx), K,
+                               L.tp(topk), L.tp(sc), L.current_stream()), "lgcn_eval_topk")
+    torch.cuda.synchronize()
+    exact = (E[:n_users][torch.from_numpy(users).long().to(DEV)].double() @ E[n_users:].double().t())   # fp64: no summation order
+    for s, u in enumerate(users):
+        exact[s, torch.from_numpy(rows[u]).long().to(DEV)] = -(1 << 10)
+    want_sc, want = torch.topk(exact, K)
+    got = topk.long()
+    assert int(got.min()) >= 0 and int(got.max()) < m_items
+    got_exact = torch.gather(exact, 1, got)
+    # fp32 rounding of a d-term dot product accumulated in any order: <= d eps sum|a_k b_k| in the worst case; sqrt(d) of it for
+    # rounding errors of random sign, taken twice (measured: 0.3 of this bound)
+    tol = 2.0 * np.sqrt(d) * EPS32 * float(E[:n_users].norm(dim=1).max()) * float(E[n_users:].norm(dim=1).max())
+    assert float((got_exact - sc.double()).abs().max()) < tol                      # the scores it reports are those items' scores
+    assert bool((got_exact > -1000).all())                                         # no train positive returned (K << unmasked items)
+    # rank by rank the same score up to that rounding (ids may swap only inside such a tie)
+    assert float((got_exact - want_sc).abs().max()) < tol
+    assert float((got == want).float().mean()) > 0.999
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+    for s in range(n_eval):
+        assert len(set(got[s].tolist())) == K
 
 
 @pytest.mark.parametrize("which", ["lastfm", "tiny"])
