@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
     "lgcn_eval_topk": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_eval_topk_fp32": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_eval_metrics": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),

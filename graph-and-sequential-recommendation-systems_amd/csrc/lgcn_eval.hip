@@ -42,6 +42,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 template <typename IDT> struct ListId;
 template <> struct ListId<int32_t> { static constexpr int32_t EMPTY = -1; static constexpr int PAD = 1; };
 template <> struct ListId<uint16_t> { static constexpr uint16_t EMPTY = 0xffffu; static constexpr int PAD = 0; };
+#ifndef EVAL_NBUF
+#define EVAL_NBUF 2
+#endif
+#ifndef EVAL_SPLIT3
+#define EVAL_SPLIT3 1          /* compact form: fp32 scores from six bf16 product planes (0: fp32 matrix instructions) */
+#endif
 #define EVAL_ID16_MAX_TILES 2047        /* 2047 * 32 + 31 < 0xffff */
 
 struct EvalArgs {
@@ -55,17 +61,59 @@ struct EvalArgs {
     int32_t *part_items; float *part_scores;      // [n_eval, gridDim.y, K] or NULL (gridDim.y == 1: straight to out_*)
 };
 
-template <int D, int KS, typename IDT, int WGS>        // KS: list slots per lane (a multiple of 4, >= K); WGS: workgroups per CU
+// c ? hi : lo.  The empty asm keeps the compiler from folding a tree of these over vector elements into ONE dynamically
+// indexed element, which it lowers through scratch memory or an LDS copy of the vector.
+static __device__ __forceinline__ float pick(bool c, float hi, float lo) {
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    return c ? hi : lo;
+}
+
+// SPLIT3: the fp32 product on the bf16 matrix cores.  Every fp32 value is EXACTLY the sum of three bf16 values
+// (x = h + m + l: 8 + 8 + 8 significant bits, by truncation: h = x & 0xffff0000, m = (x - h) & 0xffff0000, l = x - h - m,
+// every subtraction exact), and every bf16 x bf16 product is exact in fp32, so
+//     a . b = sum_k (ah + am + al)(bh + bm + bl)
+// is accumulated from the six product planes hh, hm, mh, hl, lh, mm (smallest first) by v_mfma_f32_32x32x16_bf16 -- 24 MFMAs of
+// 8 passes per 32 x 32 x 64 block instead of 32 of 16 passes.  The three planes left out (ml, lm, ll) are below 2^-23 of
+// |a_k b_k| per term: the rounding an fp32 dot product of this length carries anyway (the ranking is fp32-accurate, not
+// bit-identical to any one fp32 summation order -- neither is the reference's sgemm).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+struct Planes2 { uint32_t h, m, l; };                        // two consecutive values, bf16 pairs (low half = first value)
+static __device__ __forceinline__ Planes2 split3(float x0, float x1) {
+    const uint32_t M = 0xffff0000u;
+    const float h0 = __uint_as_float(__float_as_uint(x0) & M), h1 = __uint_as_float(__float_as_uint(x1) & M);
+    const float r0 = x0 - h0, r1 = x1 - h1;
+    const float m0 = __uint_as_float(__float_as_uint(r0) & M), m1 = __uint_as_float(__float_as_uint(r1) & M);
+    const float l0 = r0 - m0, l1 = r1 - m1;
+    Planes2 o;
+    o.h = (__float_as_uint(h0) >> 16) | __float_as_uint(h1);
+    o.m = (__float_as_uint(m0) >> 16) | __float_as_uint(m1);
+    o.l = (__float_as_uint(l0) >> 16) | (__float_as_uint(l1) & M);
+    return o;
+}
+static __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int D, int KS, typename IDT, int WGS, int NBUF = 2, bool SPLIT3 = false>
+                                                                // KS: list slots per lane (a multiple of 4, >= K); WGS: workgroups per CU;
+                                                                // NBUF: item tile buffers in LDS (1: one more barrier per tile)
 __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     constexpr int HALF = D / 2, RS = D + 4;            // row stride of the LDS item tile (floats)
+    // SPLIT3: three bf16 planes per tile, rows of D + 8 bf16 (144 bytes at d = 64: the 16-byte reads of 16 lanes at one
+    // column start 36 banks apart and cover the 64 banks once)
+    constexpr int RSB = D + 8, NCH = D / 16, PLANE_B = 32 * RSB * 2;
+    constexpr int TILE_F = SPLIT3 ? 3 * PLANE_B / 4 : 32 * RS;
     constexpr int LPT = 32 * D * 4 / 16 / 256;          // 16-byte pieces per thread per item tile
     static_assert(LPT >= 1, "tile smaller than the workgroup");
-    __shared__ __attribute__((aligned(16))) float tile_lds[2][32 * RS];
+    __shared__ __attribute__((aligned(16))) float tile_lds[NBUF][TILE_F];
     // per-lane candidate lists: KS slots (slots >= K hold +inf: never the minimum, never output),
     // 16-byte aligned rows so the minimum scan is KS/4 independent ds_read_b128
     // (row stride KS floats = 80 / 128 bytes: 16 lanes' 16-byte reads start 20 / 32 banks apart and cover the 64 banks once)
-    __shared__ __attribute__((aligned(16))) float list_s[256][KS];
-    __shared__ IDT list_i[256][KS + ListId<IDT>::PAD];
+    constexpr int KSP = (KS + 7) / 8 * 8, KH = KSP / 2;       // slots padded so that each of a user's two lanes scans KH of them
+    __shared__ __attribute__((aligned(16))) float list_s[128][KSP];
+    __shared__ IDT list_i[128][KS + ListId<IDT>::PAD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int K = a.K;
@@ -75,8 +123,17 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     const int64_t slot = (int64_t)blockIdx.x * 128 + wid * 32 + j;
     const bool have = slot < a.n_eval;
     const int32_t uid = have ? a.users[slot] : 0;
-    float b[HALF];
-    {
+    float b[SPLIT3 ? 1 : HALF];
+    u32x4 bh[SPLIT3 ? NCH : 1], bm[SPLIT3 ? NCH : 1], bl[SPLIT3 ? NCH : 1];   // SPLIT3: k = 16 c + 8 h + [0, 8) of MFMA step c
+    if constexpr (SPLIT3) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const float *up = a.E + (int64_t)uid * D + 16 * c + 8 * h;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(up), v1 = *reinterpret_cast<const f32x4 *>(up + 4);
+            const Planes2 p0 = split3(v0.x, v0.y), p1 = split3(v0.z, v0.w), p2 = split3(v1.x, v1.y), p3 = split3(v1.z, v1.w);
+            bh[c] = u32x4{p0.h, p1.h, p2.h, p3.h}; bm[c] = u32x4{p0.m, p1.m, p2.m, p3.m}; bl[c] = u32x4{p0.l, p1.l, p2.l, p3.l};
+        }
+    } else {
         const float *up = a.E + (int64_t)uid * D + h * HALF;
 #pragma unroll
         for (int s = 0; s < HALF; s += 4) {
@@ -99,9 +156,10 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
         if (tp < tend) nid = a.train_idx[tp];
         if (tp + 1 < tend) nnid = a.train_idx[tp + 1];
     }
-    for (int k = 0; k < KS; k++) { list_s[tid][k] = k < K ? EVAL_NEG_INF : 3.0e38f; list_i[tid][k] = ListId<IDT>::EMPTY; }
+    const int ul = wid * 32 + j;                               // the user's list (shared by its two lanes)
+    if (h == 0) for (int k = 0; k < KSP; k++) { list_s[ul][k] = k < K ? EVAL_NEG_INF : 3.0e38f; if (k < KS) list_i[ul][k] = ListId<IDT>::EMPTY; }
     const int id0 = sizeof(IDT) == 2 ? t_begin * 32 : 0;       // list ids are stored relative to this
-    float thr = EVAL_NEG_INF;      // the lane's K-th best so far
+    float thr = EVAL_NEG_INF;      // the user's K-th best so far (the same value in both lanes)
     int pmin = 0;                  // where it sits in the list
 
     // piece p of a tile: item row p / (D/4), 16-byte column p % (D/4)
@@ -118,14 +176,22 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const int p = tid + q * 256, r = p / (D / 4), c = p % (D / 4);
-            *reinterpret_cast<f32x4 *>(&tile_lds[buf][r * RS + c * 4]) = pre[q];
+            if constexpr (SPLIT3) {                             // split once per workgroup, not once per wave
+                const Planes2 p0 = split3(pre[q].x, pre[q].y), p1 = split3(pre[q].z, pre[q].w);
+                char *dst = reinterpret_cast<char *>(tile_lds[buf]) + (r * RSB + 4 * c) * 2;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(p0.h, p1.h);
+                *reinterpret_cast<uint2 *>(dst + PLANE_B) = make_uint2(p0.m, p1.m);
+                *reinterpret_cast<uint2 *>(dst + 2 * PLANE_B) = make_uint2(p0.l, p1.l);
+            } else {
+                *reinterpret_cast<f32x4 *>(&tile_lds[buf][r * RS + c * 4]) = pre[q];
+            }
         }
     };
     load_tile(t_begin);
-    store_tile(t_begin & 1);
+    store_tile(NBUF == 2 ? t_begin & 1 : 0);
     __syncthreads();
     for (int t = t_begin; t < t_end; t++) {
-        const int buf = t & 1;
+        const int buf = NBUF == 2 ? t & 1 : 0;
         if (t + 1 < t_end) load_tile(t + 1);                   // in flight under this tile's MFMAs
         // ---- mask of this tile's train positives for my user
         const int base = t * 32;
@@ -138,14 +204,37 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
         mask = __shfl(mask, j);                                 // lane j (h = 0) holds the user's mask
         // ---- 32 items x 32 users: scores[item i][user j] = sum_k I[i][k] U[j][k]
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float *arow = &tile_lds[buf][j * RS + h * HALF];  // A operand: lane (i = j, h) holds item i's half row
+        if constexpr (SPLIT3) {
+            const char *arow = reinterpret_cast<const char *>(tile_lds[buf]) + (j * RSB + 8 * h) * 2;   // lane (i = j, h): k = 16 c + 8 h + [0, 8)
+            u32x4 ah[NCH], am[NCH], al[NCH];
 #pragma unroll
-        for (int s = 0; s < HALF; s += 4) {
-            const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[s + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[s + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[s + 3], acc, 0, 0, 0);
+            for (int c = 0; c < NCH; c++) {
+                am[c] = *reinterpret_cast<const u32x4 *>(arow + PLANE_B + 32 * c);
+                ah[c] = *reinterpret_cast<const u32x4 *>(arow + 32 * c);
+                al[c] = *reinterpret_cast<const u32x4 *>(arow + 2 * PLANE_B + 32 * c);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) acc = mfma_bf16(am[c], bm[c], acc);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { acc = mfma_bf16(ah[c], bl[c], acc); acc = mfma_bf16(al[c], bh[c], acc); }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { acc = mfma_bf16(ah[c], bm[c], acc); acc = mfma_bf16(am[c], bh[c], acc); }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) acc = mfma_bf16(ah[c], bh[c], acc);
+        } else {
+            const float *arow = &tile_lds[buf][j * RS + h * HALF];  // A operand: lane (i = j, h) holds item i's half row
+#pragma unroll
+            for (int s = 0; s < HALF; s += 4) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + s);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[s + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[s + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[s + 3], acc, 0, 0, 0);
+            }
+        }
+        if (NBUF == 1) {                                        // every wave has read the tile: the next one may overwrite it
+            __syncthreads();
+            if (t + 1 < t_end) store_tile(0);
         }
         // ---- my 16 scores: item row = (reg & 3) + 8 * (reg >> 2) + 4 * h.  First only MARK the ones that can
         //      enter the user's top K: above this lane's K-th best AND not below the partner lane's (the other
@@ -153,61 +242,89 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
         //      are inserted one per round, all lanes together: the rounds of a tile are the LARGEST number of
         //      marked scores any lane of the workgroup has (the waves meet at the tile's barrier), not the number
         //      of score positions where some lane inserts -- mid-sweep that is 1-2 rounds instead of 5-10.
-        const float othr = __shfl_xor(thr, 32);
         uint32_t pend = 0;
+        // The reference's semantics (a train positive's score IS -1024 and competes, Procedure.py:181; rows past the table do
+        // not exist) cost three instructions per score.  They can only matter while some user with a train positive in this
+        // tile has no K scores above -1024 yet, or in the table's last tile: everywhere else a train positive is simply
+        // never marked.
+        const bool exact_mask = base + 32 > a.m_items || __any(mask != 0u && !(thr >= -1024.0f));
+        if (exact_mask) {
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            float sc = acc[reg];
-            if ((mask >> row) & 1u) sc = -1024.0f;                      // Procedure.py:181
-            if (base + row >= a.m_items) sc = EVAL_NEG_INF;             // past the table
-            acc[reg] = sc;
-            if (sc > thr && sc >= othr) pend |= 1u << reg;
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float sc = acc[reg];
+                if ((mask >> row) & 1u) sc = -1024.0f;                      // Procedure.py:181
+                if (base + row >= a.m_items) sc = EVAL_NEG_INF;             // past the table
+                acc[reg] = sc;
+                if (sc > thr) pend |= 1u << reg;
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                if (acc[reg] > thr) pend |= 1u << reg;
+            // my rows' bits of the train-positive mask, in register order: nibble g of the result = rows 8 g + 4 h + [0, 4)
+            const uint32_t m2 = mask >> (4 * h);
+            pend &= ~((m2 & 0xfu) | ((m2 >> 4) & 0xf0u) | ((m2 >> 8) & 0xf00u) | ((m2 >> 12) & 0xf000u));
         }
+        // One list per USER: of its two lanes (the two halves of the tile's rows) at most one inserts per round, the lower
+        // one first; then BOTH rescan half of the list each for the new K-th best and combine through v_permlane32_swap
+        // (no LDS round trip, and neither lane idles during the scan).
         while (__any(pend != 0u)) {
-            if (pend != 0u) {
+            const uint32_t mine = pend != 0u ? 1u : 0u;
+            const u32x2 mm = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);      // .x: lower lane's, .y: upper lane's
+            const bool act = mine && (h == 0 || mm.x == 0u);
+            uint32_t did = 0u;
+            if (act) {
                 const int reg = __builtin_ctz(pend);
                 pend &= pend - 1u;
-                float sc = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; r++) sc = reg == r ? acc[r] : sc;
+                // acc[reg] for a per-lane reg: a binary select tree (4 bit tests + 15 selects; a linear chain is 15 + 15)
+                const bool b0 = reg & 1, b1 = reg & 2, b2 = reg & 4, b3 = reg & 8;
+                const float e0 = pick(b0, acc[1], acc[0]), e1 = pick(b0, acc[3], acc[2]), e2 = pick(b0, acc[5], acc[4]), e3 = pick(b0, acc[7], acc[6]);
+                const float e4 = pick(b0, acc[9], acc[8]), e5 = pick(b0, acc[11], acc[10]), e6 = pick(b0, acc[13], acc[12]), e7 = pick(b0, acc[15], acc[14]);
+                const float f0 = pick(b1, e1, e0), f1 = pick(b1, e3, e2), f2 = pick(b1, e5, e4), f3 = pick(b1, e7, e6);
+                const float sc = pick(b3, pick(b2, f3, f2), pick(b2, f1, f0));
                 if (sc > thr) {                                         // thr may have risen since the marking
                     const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    list_s[tid][pmin] = sc; list_i[tid][pmin] = (IDT)(base + row - id0);
-                    // new minimum: all slots read at once (no dependent LDS round trips), then a register scan
-                    f32x4 q[KS / 4];
-#pragma unroll
-                    for (int k4 = 0; k4 < KS / 4; k4++) q[k4] = *reinterpret_cast<const f32x4 *>(&list_s[tid][4 * k4]);
-                    float m = q[0].x; int pm = 0;
-#pragma unroll
-                    for (int k = 1; k < KS; k++) { const float v = q[k / 4][k % 4]; if (v < m) { m = v; pm = k; } }
-                    thr = m; pmin = pm;
+                    list_s[ul][pmin] = sc; list_i[ul][pmin] = (IDT)(base + row - id0);
+                    did = 1u;
                 }
+            }
+            const u32x2 dd = __builtin_amdgcn_permlane32_swap(did, did, false, false);
+            if (dd.x | dd.y) {
+                // (the wave's LDS accesses execute in program order: the partner's write above is visible to these reads)
+                f32x4 q[KH / 4];
+#pragma unroll
+                for (int k4 = 0; k4 < KH / 4; k4++) q[k4] = *reinterpret_cast<const f32x4 *>(&list_s[ul][h * KH + 4 * k4]);
+                float m = q[0].x; int pm = 0;
+#pragma unroll
+                for (int k = 1; k < KH; k++) { const float v = q[k / 4][k % 4]; if (v < m) { m = v; pm = k; } }
+                pm += h * KH;
+                const u32x2 mv = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                const u32x2 pv = __builtin_amdgcn_permlane32_swap((uint32_t)pm, (uint32_t)pm, false, false);
+                const float m0 = __uint_as_float(mv.x), m1 = __uint_as_float(mv.y);
+                const bool lower = m0 <= m1;                            // ties: the first slot, as one lane's scan would
+                thr = lower ? m0 : m1; pmin = (int)(lower ? pv.x : pv.y);
             }
         }
-        if (t + 1 < t_end) store_tile(buf ^ 1);
+        if (NBUF == 2 && t + 1 < t_end) store_tile(buf ^ 1);
         __syncthreads();
     }
-    // ---- merge the two lanes of a user, sort descending (ties: lower item id first)
+    // ---- sort the user's list descending (ties: lower item id first)
     __syncthreads();
     if (h == 0 && have) {
-        const int other = tid + 32;
         for (int r = 0; r < K; r++) {
-            float best = EVAL_NEG_INF * 2.0f; int bi = 0x7fffffff, bw = -1, bk = 0;
-            for (int w = 0; w < 2; w++) {
-                const int src = w ? other : tid;
-                for (int k = 0; k < K; k++) {
-                    const float v = list_s[src][k]; const IDT raw = list_i[src][k];
-                    const int id = id0 + (int)raw;
-                    if (raw != ListId<IDT>::EMPTY && (v > best || (v == best && id < bi))) { best = v; bi = id; bw = src; bk = k; }
-                }
+            float best = EVAL_NEG_INF * 2.0f; int bi = 0x7fffffff, bk = -1;
+            for (int k = 0; k < K; k++) {
+                const float v = list_s[ul][k]; const IDT raw = list_i[ul][k];
+                const int id = id0 + (int)raw;
+                if (raw != ListId<IDT>::EMPTY && (v > best || (v == best && id < bi))) { best = v; bi = id; bk = k; }
             }
-            if (bw >= 0) list_i[bw][bk] = ListId<IDT>::EMPTY;  // taken
+            if (bk >= 0) list_i[ul][bk] = ListId<IDT>::EMPTY;   // taken
             if (a.part_items) {
                 const int64_t o = (slot * gridDim.y + blockIdx.y) * K + r;
-                a.part_items[o] = bw >= 0 ? bi : -1; a.part_scores[o] = best;
+                a.part_items[o] = bk >= 0 ? bi : -1; a.part_scores[o] = best;
             } else {
-                a.out_items[slot * K + r] = bw >= 0 ? bi : -1;
+                a.out_items[slot * K + r] = bk >= 0 ? bi : -1;
                 if (a.out_scores) a.out_scores[slot * K + r] = best;
             }
         }
@@ -287,10 +404,10 @@ __global__ void __launch_bounds__(256) k_eval_sum(const double *per_user, int32_
     }
 }
 
-extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
-                              const int32_t *users, int32_t n_eval,
-                              const int64_t *train_indptr, const int32_t *train_indices,
-                              int32_t K, int32_t *topk_items, float *topk_scores, void *stream) {
+static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
+                     const int32_t *users, int32_t n_eval,
+                     const int64_t *train_indptr, const int32_t *train_indices,
+                     int32_t K, int32_t *topk_items, float *topk_scores, void *stream, bool split3) {
     if (!E || !users || !train_indptr || !train_indices || !topk_items || n_users <= 0 || m_items <= 0 || n_eval < 0) {
         lgcn_set_error("lgcn_eval_topk: invalid argument"); return 3;
     }
@@ -322,7 +439,8 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     const dim3 grid(blocks, parts);
 #define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20, int32_t, 1>), grid, dim3(256), 0, st, a); \
                             else hipLaunchKernelGGL((k_eval_topk<DD, 32, int32_t, 1>), grid, dim3(256), 0, st, a); } while (0)
-#define EVAL_LAUNCH_SMALL(DD) do { if (id16) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS>), grid, dim3(256), 0, st, a); \
+#define EVAL_LAUNCH_SMALL(DD) do { if (id16 && split3) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, true>), grid, dim3(256), 0, st, a); \
+                                  else if (id16) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, false>), grid, dim3(256), 0, st, a); \
                                   else EVAL_LAUNCH(DD); } while (0)
     switch (d) {
     case 32: EVAL_LAUNCH_SMALL(32); break;
@@ -340,6 +458,18 @@ extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, 
     }
     if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_topk: launch failed"); return 10; }
     return 0;
+}
+
+extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d, const int32_t *users, int32_t n_eval,
+                              const int64_t *train_indptr, const int32_t *train_indices, int32_t K, int32_t *topk_items,
+                              float *topk_scores, void *stream) {
+    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, stream, EVAL_SPLIT3 != 0);
+}
+
+extern "C" int lgcn_eval_topk_fp32(const float *E, int32_t n_users, int32_t m_items, int32_t d, const int32_t *users, int32_t n_eval,
+                                   const int64_t *train_indptr, const int32_t *train_indices, int32_t K, int32_t *topk_items,
+                                   float *topk_scores, void *stream) {
+    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, stream, false);
 }
 
 extern "C" int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,

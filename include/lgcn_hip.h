@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 8
+#define LGCN_ABI_VERSION 9
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -263,7 +263,7 @@ int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t 
 /* Device: fused full-ranking evaluation -- replaces the body of Procedure.Test  */
 /* ------------------------------------------------------------------------ */
 /* For every listed user: scores against ALL items (model.getUsersRating, model.py:114-123:
- * U_b . I^T on the propagated table E[N,d] -- fp32 matrix cores, fp32 accumulate), train positives
+ * U_b . I^T on the propagated table E[N,d] -- matrix cores, fp32 accumulate, fp32-accurate), train positives
  * set to -(1<<10) (Procedure.py:177-181; CSR with int64 indptr[n_users+1] and ascending int32
  * indices = dataset.allPos), top-K (Procedure.py:183) -- in one kernel, the [users, m_items]
  * score matrix is never materialised.  topk_items [n_eval,K] int32, best first (ties: lower
@@ -272,6 +272,15 @@ int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
                    const int32_t *users, int32_t n_eval,
                    const int64_t *train_indptr, const int32_t *train_indices,
                    int32_t K, int32_t *topk_items, float *topk_scores, void *stream);
+/* The same, with every score produced by the fp32 matrix instructions (v_mfma_f32_32x32x2_f32).  lgcn_eval_topk itself
+ * computes the fp32 product on the bf16 matrix cores where it can (d <= 64, K <= 20, at most 196 K items per third of
+ * the catalogue): both operands split EXACTLY into three bf16 values each, six of the nine product planes accumulated in
+ * fp32 -- the planes left out are below the rounding of an fp32 dot product, so both entry points are fp32-accurate and
+ * may differ only where two scores tie within that rounding.  This one is the slower cross-check.          */
+int lgcn_eval_topk_fp32(const float *E, int32_t n_users, int32_t m_items, int32_t d,
+                        const int32_t *users, int32_t n_eval,
+                        const int64_t *train_indptr, const int32_t *train_indices,
+                        int32_t K, int32_t *topk_items, float *topk_scores, void *stream);
 /* Per-user precision / recall / NDCG at the cut-offs ks[n_ks] (Procedure.test_one_batch,
  * Procedure.py:89-121; utils.RecallPrecision_ATk / NDCGatK_r / getLabel, utils.py:173-217) from the
  * ranked ids and the users' test lists (CSR over the n_eval slots, ids ASCENDING per slot), in

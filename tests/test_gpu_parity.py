@@ -1107,6 +1107,14 @@ def test_eval_topk_every_sweep_form_vs_torch(pkg, m_items, d, K, n_eval):
     assert bool((sc[:, :-1] >= sc[:, 1:]).all())
     for s in range(n_eval):
         assert len(set(got[s].tolist())) == K
+    # the cross-check entry point (every score from the fp32 matrix instructions): the same lists up to ties within rounding
+    topk32 = torch.full((n_eval, K), -7, dtype=torch.int32, device=DEV)
+    sc32 = torch.empty(n_eval, K, dtype=torch.float32, device=DEV)
+    L.check(lib.lgcn_eval_topk_fp32(L.tp(E), n_users, m_items, d, L.tp(d_users), n_eval, L.tp(d_ptr), L.tp(d_idx), K,
+                                    L.tp(topk32), L.tp(sc32), L.current_stream()), "lgcn_eval_topk_fp32")
+    assert float((topk32 == topk).float().mean()) > 0.999
+    assert float((sc32.double() - sc.double()).abs().max()) < tol
+    assert float((torch.gather(exact, 1, topk32.long()) - want_sc).abs().max()) < tol
 
 
 @pytest.mark.parametrize("which", ["lastfm", "tiny"])
