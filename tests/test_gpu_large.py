@@ -121,7 +121,8 @@ def test_c5_full_shape(pkg, oracle):
         (2 n + 2) * 2^-24 * sum |v x| per element; lgcn_propagate_mean against (X_0 + .. + X_3) / 4 of those layers;
       * one fused step, fp32 and bf16 activation storage: loss against the loss recomputed from the propagated rows
         of the batch, Adam's first step bounded by lr, G64 left clean, and hub plan on / off equal to 2e-7 (loss) and
-        1e-6 (parameters: the two differ in the summation order of the hub rows only)."""
+        1e-6 (parameters: the two differ in the summation order of the hub rows only);
+      * one epoch of the device sampler -- 200 M triplets -- bit for bit the host sampler's."""
     import ctypes as C
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -236,3 +237,17 @@ def test_c5_full_shape(pkg, oracle):
             assert float(dg.max()) <= 2e-9, (act, what, float(dg.max()))
             assert float(big.max()) <= 2.0 * lr
     m._drop_device_state()
+    del m
+    torch.cuda.empty_cache()
+
+    # ---- a whole 200 M-triplet epoch of the device sampler (segments on all CUs) against the host restatement of
+    #      sampling.cpp, same seed: identical rows, and the generator ends at the same stream position
+    S = pkg.sampling
+    csr = ds.pos_csr()
+    S.seed(2020)
+    want = S.sample_negative(ds.n_users, ds.m_items, ds.trainDataSize, csr, 1)
+    tail_host = [S.randint(1 << 20) for _ in range(3)]
+    S.seed(2020)
+    got = S.sample_negative_device(ds.n_users, ds.m_items, ds.trainDataSize, csr, DEV).cpu().numpy()
+    tail_dev = [S.randint(1 << 20) for _ in range(3)]
+    assert want.shape == (E, 3) and got.dtype == np.int32 and np.array_equal(want, got) and tail_host == tail_dev

@@ -1280,6 +1280,36 @@ def test_gpu_sampler_bit_exact(pkg, oracle, tiny, tmp_path):
         assert Sg.shape == (806166, 3) and hashlib.sha256(Sg.tobytes()).hexdigest().startswith(prefix)
 
 
+def test_gpu_sampler_segments_heavy_tail_bit_exact(pkg):
+    """The segmented device sampler (rejecting (position, user) pairs on all CUs, the event walk in LDS, triplets emitted in
+    parallel) where its capacities and shortcuts are under stress: power-law degrees, hub users positive on 25-50 % of the items
+    next to each other (blocks full of pairs, segments ending early on the extra-draw budget), two users positive on 99 % of the
+    items (rejection runs longer than the budget: the walk leaves the pair list and asks the row; the one-workgroup kernel
+    finishes what the segment launches did not reach).  Rows identical to the host restatement of sampling.cpp for three
+    consecutive epochs, and the host generator ends at the same stream position."""
+    S = pkg.sampling
+    rng = np.random.Generator(np.random.PCG64(2024))
+    n_users, m_items = 3000, 2000
+    deg = np.minimum(m_items // 4, np.maximum(1, (30.0 / rng.random(n_users) ** 0.7).astype(np.int64) // 8))
+    deg[100:108] = m_items // 2                 # adjacent hubs
+    deg[1500] = deg[1501] = m_items - 20        # 99 % positive
+    deg[2999] = m_items // 3                    # the last user
+    rows = [np.sort(rng.choice(m_items, size=int(k), replace=False)).astype(np.int32) for k in deg]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = np.concatenate(rows)
+    train_num = 15 * n_users + 7
+    S.seed(31)
+    want = [S.sample_negative(n_users, m_items, train_num, (indptr, indices), 1) for _ in range(3)]
+    tail_host = [S.randint(1 << 20) for _ in range(4)]
+    S.seed(31)
+    got = [S.sample_negative_device(n_users, m_items, train_num, (indptr, indices), DEV).cpu().numpy() for _ in range(3)]
+    tail_dev = [S.randint(1 << 20) for _ in range(4)]
+    for e, (w_, g_) in enumerate(zip(want, got)):
+        bad = np.flatnonzero((w_ != g_).any(axis=1))
+        assert g_.dtype == np.int32 and bad.size == 0, (e, bad[:5], w_[bad[:3]], g_[bad[:3]])
+    assert tail_host == tail_dev
+
+
 def test_gpu_sampler_margin_falls_back_to_host(pkg, tmp_path):
     """A dense dataset (every user holds 90 % of the items: ~9 rejected negatives per triplet) exceeds the device sampler's
     stream margin (T/50 + 65536 draws): lgcn_sample_negative_device returns rc 5 WITHOUT advancing the host generator
