@@ -1229,21 +1229,25 @@ __global__ void __launch_bounds__(256) k_triplet_gate(GateArgs a) {
         }
     }
     __syncthreads();
-    // ---- phase 2: this workgroup's parameter-gradient sums over its slots, every slot's term in fixed point
+    // ---- phase 2: this workgroup's parameter-gradient sums over its slots.  The two item slots of a triplet (2 tt, 2 tt + 1) are
+    //      added in fp32 -- the same pair on every rank whatever the shard -- and each triplet's term enters the sum in fixed point:
+    //      the total does not depend on which triplets share a workgroup or a rank (half the conversions of one per slot)
     long long *out = a.partials + (int64_t)blockIdx.x * a.P;
     auto fx = [](float v) { return __double2ll_rn((double)v * FIXED_SCALE); };
+#define GATE_SUM(EXPR) _Pragma("unroll") for (int w2 = 0; w2 < GATE_S; w2 += 2) { float pr_; { const int sI = w2; pr_ = (EXPR); } { const int sI = w2 + 1; pr_ += (EXPR); } v += fx(pr_); }
     for (int i = tid; i < a.P; i += 256) {
         long long v = 0;
-        if (i < Hp) { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DA[sI * GATE_HMAX + i] * SC[sI]); }
-        else if (i < oW2) { const int k = i - Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DA[sI * GATE_HMAX + k]); }
-        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DPV[sI * D + c] * AA[sI * GATE_HMAX + k]); }
-        else if (i < oV1) { const int c = i - ob2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DPV[sI * D + c]); }
-        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]); }
-        else if (i < oV2) { const int jj = i - oc1; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DH[sI * GATE_HMAX + jj]); }
-        else if (i < oc2) { const int jj = i - oV2; _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DLOG[sI] * HR[sI * GATE_HMAX + jj]); }
-        else { _Pragma("unroll") for (int sI = 0; sI < GATE_S; sI++) v += fx(DLOG[sI]); }
+        if (i < Hp) { GATE_SUM(DA[sI * GATE_HMAX + i] * SC[sI]) }
+        else if (i < oW2) { const int k = i - Hp; GATE_SUM(DA[sI * GATE_HMAX + k]) }
+        else if (i < ob2) { const int c = (i - oW2) / Hp, k = (i - oW2) % Hp; GATE_SUM(DPV[sI * D + c] * AA[sI * GATE_HMAX + k]) }
+        else if (i < oV1) { const int c = i - ob2; GATE_SUM(DPV[sI * D + c]) }
+        else if (i < oc1) { const int jj = (i - oV1) / D2, c = (i - oV1) % D2; GATE_SUM(DH[sI * GATE_HMAX + jj] * IN[sI * D2 + c]) }
+        else if (i < oV2) { const int jj = i - oc1; GATE_SUM(DH[sI * GATE_HMAX + jj]) }
+        else if (i < oc2) { const int jj = i - oV2; GATE_SUM(DLOG[sI] * HR[sI * GATE_HMAX + jj]) }
+        else { GATE_SUM(DLOG[sI]) }
         out[i] = v;
     }
+#undef GATE_SUM
 }
 static size_t gate_lds_bytes(int D) {
     const size_t fl = (size_t)GATE_HMAX * (2 * D + 1) + (size_t)D * (GATE_HMAX + 1) + 2 * GATE_HMAX + D + 2 * GATE_HMAX

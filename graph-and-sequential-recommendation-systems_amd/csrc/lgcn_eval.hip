@@ -421,9 +421,10 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
     // K <= 20, at most 2047 tiles per part) make that three; otherwise two (d <= 64, K <= 20) or one.
     // (measured on Gowalla with int32 ids, two per CU: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
     const int ntiles = (m_items + 31) / 32;
-    const bool split = d <= 64 && K <= 20 && m_items >= 4096;
-    const bool id16 = split && (ntiles + EVAL_PARTS - 1) / EVAL_PARTS + 1 <= EVAL_ID16_MAX_TILES;
-    const int parts = id16 ? EVAL_PARTS : split ? 2 : 1;
+    const bool split = d <= 128 && K <= 20 && m_items >= 4096;
+    const int want = d <= 64 ? EVAL_PARTS : 2;                 // d = 128: 256 registers, two workgroups per CU
+    const bool id16 = split && (ntiles + want - 1) / want + 1 <= EVAL_ID16_MAX_TILES;
+    const int parts = id16 ? want : split ? 2 : 1;
     void *tmp = nullptr;
     bool tmp_sync = false;
     if (parts > 1) {
@@ -445,7 +446,11 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
     switch (d) {
     case 32: EVAL_LAUNCH_SMALL(32); break;
     case 64: EVAL_LAUNCH_SMALL(64); break;
-    case 128: EVAL_LAUNCH(128); break;
+    case 128:
+        if (id16 && split3) hipLaunchKernelGGL((k_eval_topk<128, 20, uint16_t, 2, 1, true>), grid, dim3(256), 0, st, a);
+        else if (id16) hipLaunchKernelGGL((k_eval_topk<128, 20, uint16_t, 2, 2, false>), grid, dim3(256), 0, st, a);
+        else EVAL_LAUNCH(128);
+        break;
     case 256: EVAL_LAUNCH(256); break;
     default: if (tmp) { if (tmp_sync) (void)hipFree(tmp); else (void)hipFreeAsync(tmp, st); } lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
     }

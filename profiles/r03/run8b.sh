@@ -25,3 +25,6 @@ timeout -k 10 600 python tools/variants_time.py 2>> $OUT/variants.err | tail -1 
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_variants/trace -- python3 $ROOT/tools/variants_time.py > $OUT/trace_variants.log 2>&1 || echo "trace variants failed" | tee -a $OUT/status.log
 python3 $ROOT/profiles/summarize.py $OUT/trace_variants > $OUT/trace_variants_summary.txt 2>&1; head -24 $OUT/trace_variants_summary.txt | cut -c1-140
+cd $ROOT
+timeout -k 10 300 python tools/sampler_time.py 2>> $OUT/sampler.err | tail -1 | tee $OUT/sampler_time.json | cut -c1-400
+timeout -k 10 600 python tools/gowalla_trajectory.py 2>> $OUT/traj.err | tail -3 | tee $OUT/gowalla_trajectory.txt | cut -c1-600
