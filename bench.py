@@ -251,7 +251,13 @@ def main():
         return {"bound": "hbm", "kernel": f"k_spmm<{d},{'float' if adt == 0 else 'bf16'}> (dense CSR-SpMM layer)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": note, "algorithmic_bytes_per_launch": bytes_spmm,
-                "avg_launch_us": t_spmm * 1e6, "gather_bytes_upper_bound": nnz * d * s}
+                "avg_launch_us": t_spmm * 1e6, "gather_bytes_upper_bound": nnz * d * s,
+                # the row gathers themselves (nnz rows of d*s bytes, whatever level serves them) against the chip-wide rate the
+                # guide measures for rows gathered out of the XCDs' L2 (MI355X_MICROARCH.md "Indexed rows": 66-73 GB/s per CU =
+                # 16.8-18.8 TB/s; = 16 channels x 64 B/clk x 8 XCDs): where the table fits L2 + Infinity Cache this, not HBM, is
+                # the roof the kernel sits under; tables beyond the caches (synthetic-10m) are bounded by HBM through `traffic`
+                "gather": {"bound": "l2-gather", "achieved": nnz * d * s / t_spmm / 1e9, "peak": 17800.0, "unit": "GB/s",
+                           "frac": nnz * d * s / t_spmm / 1e9 / 17800.0}}
 
     if a.spmm_only:
         reps = a.spmm_reps if a.workload != "synthetic-10m" else min(a.spmm_reps, 5)
