@@ -81,7 +81,6 @@ ncclResult_t run_ops(Loop *l, hipStream_t st) {
 }
 
 ncclResult_t lb_group_start() { return ncclSuccess; }             // (state lives in the communicator: see lb_broadcast)
-ncclResult_t lb_group_end() { return ncclSuccess; }
 
 ncclResult_t lb_all_gather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
     Loop *l = loop_of(c); Group *g = l->g;
