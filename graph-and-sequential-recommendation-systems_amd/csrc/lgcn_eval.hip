@@ -45,6 +45,9 @@ template <> struct ListId<uint16_t> { static constexpr uint16_t EMPTY = 0xffffu;
 #ifndef EVAL_NBUF
 #define EVAL_NBUF 2
 #endif
+#ifndef EVAL_PUB_TILES
+#define EVAL_PUB_TILES 16        /* tiles between two exchanges of the parts' K-th best (a power of two; 0: never) */
+#endif
 #ifndef EVAL_SPLIT3
 #define EVAL_SPLIT3 1          /* compact form: fp32 scores from six bf16 product planes (0: fp32 matrix instructions) */
 #endif
@@ -59,6 +62,10 @@ struct EvalArgs {
     // the item sweep split over gridDim.y workgroups per user block (two co-resident workgroups per CU overlap
     // one's list maintenance with the other's MFMAs): each writes its sorted partial list here, k_eval_merge picks
     int32_t *part_items; float *part_scores;      // [n_eval, gridDim.y, K] or NULL (gridDim.y == 1: straight to out_*)
+    // The parts of a user's sweep tell each other their K-th best so far ([gridDim.y][n_eval], NaN = nothing yet; or NULL):
+    // K items at or above a part's K-th best exist, so every other part may use it as a floor for what it still inserts.
+    // Any value ever published is valid, however stale -- the exchange only prunes, it never decides.
+    float *thr_pub;
 };
 
 // c ? hi : lo.  The empty asm keeps the compiler from folding a tree of these over vector elements into ONE dynamically
@@ -159,7 +166,7 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     const int ul = wid * 32 + j;                               // the user's list (shared by its two lanes)
     if (h == 0) for (int k = 0; k < KSP; k++) { list_s[ul][k] = k < K ? EVAL_NEG_INF : 3.0e38f; if (k < KS) list_i[ul][k] = ListId<IDT>::EMPTY; }
     const int id0 = sizeof(IDT) == 2 ? t_begin * 32 : 0;       // list ids are stored relative to this
-    float thr = EVAL_NEG_INF;      // the user's K-th best so far (the same value in both lanes)
+    float thr = EVAL_NEG_INF;      // the user's K-th best so far (the same value in both lanes), or the other parts' if that is higher
     int pmin = 0;                  // where it sits in the list
 
     // piece p of a tile: item row p / (D/4), 16-byte column p % (D/4)
@@ -190,8 +197,16 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     load_tile(t_begin);
     store_tile(NBUF == 2 ? t_begin & 1 : 0);
     __syncthreads();
+    typedef __attribute__((address_space(1))) float gf32;
     for (int t = t_begin; t < t_end; t++) {
         const int buf = NBUF == 2 ? t & 1 : 0;
+        if (a.thr_pub && have && ((t - t_begin) & (EVAL_PUB_TILES - 1)) == EVAL_PUB_TILES - 1) {
+            // (agent-scope accesses: the parts run on different XCDs, whose L2s do not see each other's plain stores)
+            if (h == 0) __hip_atomic_store((gf32 *)(a.thr_pub + (int64_t)blockIdx.y * a.n_eval + slot), thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < (int)gridDim.y; q++)
+                if (q != (int)blockIdx.y)
+                    thr = fmaxf(thr, __hip_atomic_load((gf32 *)(a.thr_pub + (int64_t)q * a.n_eval + slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // fmaxf drops a NaN
+        }
         if (t + 1 < t_end) load_tile(t + 1);                   // in flight under this tile's MFMAs
         // ---- mask of this tile's train positives for my user
         const int base = t * 32;
@@ -303,7 +318,8 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
                 const u32x2 pv = __builtin_amdgcn_permlane32_swap((uint32_t)pm, (uint32_t)pm, false, false);
                 const float m0 = __uint_as_float(mv.x), m1 = __uint_as_float(mv.y);
                 const bool lower = m0 <= m1;                            // ties: the first slot, as one lane's scan would
-                thr = lower ? m0 : m1; pmin = (int)(lower ? pv.x : pv.y);
+                thr = fmaxf(lower ? m0 : m1, thr);          // (thr never falls: it may already stand above the list's minimum, on another part's word)
+                pmin = (int)(lower ? pv.x : pv.y);
             }
         }
         if (NBUF == 2 && t + 1 < t_end) store_tile(buf ^ 1);
@@ -413,7 +429,7 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
     }
     if (K < 1 || K > EVAL_KMAX || K > m_items) { lgcn_set_error("lgcn_eval_topk: K must be in 1..32 and <= m_items"); return 3; }
     if (n_eval == 0) return 0;
-    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr};
+    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr, nullptr};
     const unsigned blocks = (unsigned)((n_eval + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     // The item sweep is split over `parts` workgroups per user block, as many as fit a CU together, so that one's list
@@ -429,13 +445,19 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
     bool tmp_sync = false;
     if (parts > 1) {
         const size_t n = (size_t)n_eval * parts * K;
-        if (hipMallocAsync(&tmp, n * (sizeof(int32_t) + sizeof(float)), st) != hipSuccess) {
+        const size_t lists = (n * (sizeof(int32_t) + sizeof(float)) + 255) & ~(size_t)255;
+        const size_t pub = EVAL_PUB_TILES > 0 ? (size_t)parts * n_eval * sizeof(float) : 0;
+        if (hipMallocAsync(&tmp, lists + pub, st) != hipSuccess) {
             (void)hipGetLastError();
             tmp = nullptr;
-            if (hipMalloc(&tmp, n * (sizeof(int32_t) + sizeof(float))) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: cannot allocate the partial lists"); return 4; }
+            if (hipMalloc(&tmp, lists + pub) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: cannot allocate the partial lists"); return 4; }
             tmp_sync = true;       // no stream-ordered pool on this runtime: plain allocation, freed after a synchronise
         }
         a.part_items = (int32_t *)tmp; a.part_scores = (float *)((int32_t *)tmp + n);
+        if (pub) {
+            a.thr_pub = (float *)((char *)tmp + lists);
+            if (hipMemsetAsync(a.thr_pub, 0xff, pub, st) != hipSuccess) { lgcn_set_error("lgcn_eval_topk: memset failed"); return 10; }     // NaN = nothing published
+        }
     }
     const dim3 grid(blocks, parts);
 #define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20, int32_t, 1>), grid, dim3(256), 0, st, a); \
