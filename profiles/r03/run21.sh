@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU run 21: SQ counters of k_eval_topk (what is a tile's 9 300 cycles per wave made of?)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03y
+OUT=$ROOT/gpurun_out/r03ae
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_e1 -- python3 $ROOT/tools/eval_time.py > $OUT/e1.log 2>&1 || echo "e1 failed"
