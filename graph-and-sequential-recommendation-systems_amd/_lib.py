@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -34,6 +34,7 @@ class TrainConfig(C.Structure):
         ("item_pop", _vp), ("gate_params", _vp), ("gate_adam_m", _vp), ("gate_adam_v", _vp), ("gate_grad", _vp),
         ("pop_hidden", C.c_int32), ("gate_hidden", C.c_int32),
         ("gate_entropy_coeff", C.c_float), ("pop_gate_temp", C.c_float),
+        ("reg_ego", C.c_int32),
     ]
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "lgcn_sample_negative": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_int, _vp]),
     "lgcn_sample_negative_by_user": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "lgcn_sample_negative_device_workspace": (C.c_int64, [C.c_int, C.c_int64]),
+    "lgcn_sampler_test_margin": (None, [C.c_int64, C.c_int64]),
     "lgcn_sample_negative_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "lgcn_np_seed": (None, [C.c_uint32]),
     "lgcn_sample_python": (C.c_int64, [C.c_int, C.c_int, C.c_int64, _vp, _vp, _vp]),
@@ -79,6 +81,7 @@ SIGNATURES = {
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),
     "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lgcn_dp_allreduce_sum_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "lgcn_dp_init_loopback": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lgcn_dp_destroy": (None, [_vp]),
     "lgcn_dp_world": (C.c_int, [_vp]),

@@ -348,6 +348,7 @@ struct SpmmArgs {
     float step_size, bc2_sqrt, w1, beta2, omb2, eps;
     int remap;
     const float *selfX;           // M_ADDSELF: Y[row] = selfX[row] + (A X)[row]  (item-item smoothing, model.py:228-229)
+    int32_t *cnt; float lam;      // reg_ego: slots of the batch naming each row (zeroed as consumed), decay / B: grad += lam * cnt[row] * P[row]
 };
 
 enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4, M_ADDSELF = 8 };
@@ -379,6 +380,13 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         V p, m, v;
         if (pre && pre->have) { p = pre->p; m = pre->m; v = pre->v; }
         else { p = loadv<C>(a.P + off); m = loadv<C>(a.M + off); v = loadv<C>(a.V + off); }
+        if ((MODE & M_ADDG) && a.cnt && flagged) {
+            // upstream LightGCN's L2 term (cfg.reg_ego): d(decay * reg)/dE0[row] = decay/B * (slots naming the row) * E0[row],
+            // added to the propagated gradient here, where E0[row] is in registers anyway
+            const int n_slots = a.cnt[row];
+            acc = acc + (a.lam * (float)n_slots) * p;
+            if (l == 0) a.cnt[row] = 0;                 // consumed (all lanes of the row belong to this wave: read before write)
+        }
         m = m + a.w1 * (acc - m);                       // exp_avg.lerp_(grad, 1-beta1)
         v = v * a.beta2 + (a.omb2 * acc) * acc;         // mul_(beta2).addcmul_(g,g,1-beta2)
         V denom;
@@ -804,6 +812,8 @@ struct BprArgs {
     int32_t terms_off, terms_stride;
     int32_t *err;
     int32_t dense_last;   // X_K exists densely (Xl[K]): the slot rows are read, not gathered
+    int32_t reg_ego;      // L2 term on the tables' own rows X0[row] (upstream LightGCN) instead of the propagated rows (the fork)
+    int32_t *cnt;         // reg_ego: per-row count of the batch slots naming the row (bumped where the row is flagged), or NULL
 };
 
 __device__ __forceinline__ float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
@@ -823,13 +833,20 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
 // at a 32-byte stride and cost 9 of a 13.7 us kernel.)  x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
 // r = |e_u|^2+|e_p|^2+|e_n|^2 ; gradient rows w.r.t. the propagated table -> fixed-point
 // atomics into G64 + row flags (single GPU / dense DP) or the exchange block (DP rows).
+// reg_ego: u0 / p0 / n0 = the slots' rows of the table itself; the L2 term is theirs and its gradient never enters G
+// (the Adam epilogue adds it from the slot counts), so the gradient rows carry no lam term.
 template <int D>
-__device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l, const float *u, const float *p, const float *n) {
+__device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l, const float *u, const float *p, const float *n,
+                                                  const float *u0 = nullptr, const float *p0 = nullptr, const float *n0 = nullptr) {
     constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
     float ps = 0.f, ns = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
+    const bool ego = a.reg_ego != 0;
+    const float lam = ego ? 0.f : a.lam;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
-        ps += u[j] * p[j]; ns += u[j] * n[j]; ru += u[j] * u[j]; rp += p[j] * p[j]; rn += n[j] * n[j];
+        ps += u[j] * p[j]; ns += u[j] * n[j];
+        const float ur = ego ? u0[j] : u[j], pr = ego ? p0[j] : p[j], nr = ego ? n0[j] : n[j];
+        ru += ur * ur; rp += pr * pr; rn += nr * nr;
     }
     float rr = ru + rp + rn;
 #pragma unroll
@@ -851,7 +868,7 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
     for (int c = 0; c < 3; c++) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
-            float g = c == 0 ? gb * (p[j] - n[j]) + a.lam * u[j] : (c == 1 ? gb * u[j] + a.lam * p[j] : (-gb) * u[j] + a.lam * n[j]);
+            float g = c == 0 ? gb * (p[j] - n[j]) + lam * u[j] : (c == 1 ? gb * u[j] + lam * p[j] : (-gb) * u[j] + lam * n[j]);
             if (a.G64 && !tbad)
                 atomicAdd((unsigned long long *)(a.G64 + rows[c] * D + j * LPT + l),
                           (unsigned long long)__double2ll_rn((double)g * FIXED_SCALE));
@@ -859,6 +876,7 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
         }
         if (a.G64 && !tbad && l == 0) {
             atomicOr(a.bitmap + (rows[c] >> 5), 1u << (rows[c] & 31));
+            if (a.cnt) atomicAdd(a.cnt + rows[c], 1);
             if (a.item_bitmap && c > 0) { const int64_t it = rows[c] - a.n_users; atomicOr(a.item_bitmap + (it >> 5), 1u << (it & 31)); }
         }
     }
@@ -914,7 +932,7 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
 
 // TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
 template <int D, typename TG, typename TI, bool BIG>
-__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[4][D], float (*base)[D]) {
+__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[4][D], float (*base)[D], float (*ego)[D]) {
     typedef Geo<D, TG, false> G;
     constexpr int C = G::CPL, LPR = G::LPR, UN = 64 * ROWS_UNIT_TILES;
     constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT;      // lane = column (mod 64) layout of the finishing steps
@@ -936,6 +954,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
             for (int j = 0; j < CPT; j++) {
                 const int col = j * LPT + lane;
                 float s = a.X0[row * D + col];
+                if (a.reg_ego) ego[c][col] = s;
                 for (int k = 1; k < a.K; k++) s += (float)((const TI *)a.Xl[k])[row * D + col];
                 base[c][col] = s;
             }
@@ -975,7 +994,14 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
             e[c][j] = (base[c][col] + xk) / div;
         }
     }
-    triplet_loss_regs<D>(a, b, lane, e[0], e[1], e[2]);
+    if (a.reg_ego) {
+        float e0[3][CPT];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int j = 0; j < CPT; j++) e0[c][j] = ego[c][j * LPT + lane];
+        triplet_loss_regs<D>(a, b, lane, e[0], e[1], e[2], e0[0], e0[1], e0[2]);
+    } else triplet_loss_regs<D>(a, b, lane, e[0], e[1], e[2]);
 }
 
 template <int D, typename TI, bool BIG>
@@ -983,12 +1009,13 @@ __global__ void __launch_bounds__(256, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 :
     __shared__ int2 stage_lds[4][TILE_ST];
     __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
     __shared__ float base_lds[3][D];
+    __shared__ float ego_lds[3][D];          // reg_ego: the slots' rows of the table itself
     // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
         a.stale_bitmap[i] = 0u;
     int2 *stage = stage_lds[threadIdx.x >> 6];
-    if (a.K == 1) triplet_body<D, float, TI, BIG>(a, a.X0, stage, part_lds, base_lds);
-    else triplet_body<D, TI, TI, BIG>(a, a.Xl[a.K - 1], stage, part_lds, base_lds);
+    if (a.K == 1) triplet_body<D, float, TI, BIG>(a, a.X0, stage, part_lds, base_lds, ego_lds);
+    else triplet_body<D, TI, TI, BIG>(a, a.Xl[a.K - 1], stage, part_lds, base_lds, ego_lds);
 }
 
 // The same when the last layer was propagated densely (cfg.dense_last): e = mean_k X_k[row] is K+1 row reads per slot,
@@ -1008,18 +1035,19 @@ __global__ void __launch_bounds__(256) k_triplet_dense(BprArgs a) {
     if (bad && l == 0) atomicExch(a.err, 1);
     const int64_t rows[3] = {bad ? 0 : (int64_t)a.users[b], bad ? 0 : (int64_t)a.pos[b] + a.n_users, bad ? 0 : (int64_t)a.neg[b] + a.n_users};
     const float div = (float)(a.K + 1);
-    float e[3][CPT];
+    float e[3][CPT], e0[3][CPT];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
 #pragma unroll
         for (int j = 0; j < CPT; j++) {
             const int64_t o = rows[c] * D + j * LPT + l;
             float s = a.X0[o];
+            e0[c][j] = s;
             for (int k = 1; k <= a.K; k++) s += (float)((const TI *)a.Xl[k])[o];
             e[c][j] = s / div;
         }
     }
-    triplet_loss_regs<D>(a, b, l, e[0], e[1], e[2]);
+    triplet_loss_regs<D>(a, b, l, e[0], e[1], e[2], e0[0], e0[1], e0[2]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1337,6 +1365,7 @@ struct SlotArgs {
     float ent_coeff;
     int64_t blk;                                           // floats per rank in `gathered` (0: default layout)
     uint32_t *item_bitmap;                                 // DP scatter with item-item smoothing: items named by the global batch
+    int32_t *cnt;                                          // reg_ego: per-row slot counts (k_scatter / k_flag_rows bump, k_finish clears), or NULL
 };
 
 // DP: order-independent scatter of every rank's gradient rows into G64 (+ row flags)
@@ -1361,6 +1390,7 @@ __global__ void __launch_bounds__(256) k_scatter(SlotArgs a) {
                   (unsigned long long)__double2ll_rn((double)src[j * LPT + l] * FIXED_SCALE));
     if (l == 0) {
         atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+        if (a.cnt) atomicAdd(a.cnt + row, 1);
         if (a.item_bitmap && c > 0) { const int64_t it = row - a.n_users; atomicOr(a.item_bitmap + (it >> 5), 1u << (it & 31)); }
     }
 }
@@ -1385,7 +1415,10 @@ __global__ void __launch_bounds__(256) k_flag_rows(SlotArgs a) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= 3 * a.B) return;
     const int64_t row = slot_row(s / a.B, s % a.B, a.users, a.pos, a.neg, a.n_users, a.N);
-    if (row >= 0) atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+    if (row >= 0) {
+        atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
+        if (a.cnt) atomicAdd(a.cnt + row, 1);          // dense form: every rank counts the whole global batch itself (part 1 does not)
+    }
 }
 
 // End of step: zero what the step touched (G64 rows, bitmap words of the batch rows);
@@ -1400,7 +1433,7 @@ __global__ void __launch_bounds__(256) k_finish(SlotArgs a) {
         if (row >= 0) {
                     i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + row * D + l * 4);
             q[0] = i64x2{0, 0}; q[1] = i64x2{0, 0};
-            if (l == 0) a.bitmap[row >> 5] = 0u;
+            if (l == 0) { a.bitmap[row >> 5] = 0u; if (a.cnt) a.cnt[row] = 0; }
         }
     }
     // the same single-wave, fixed-order reduction as the fused finish of the last SpMM: identical bits
@@ -1813,6 +1846,7 @@ struct lgcn_ctx {
     uint32_t *item_bitmap;        // [ceil(m_items/32)] items named by the batch (item-item backward), library-owned
     long long *gate_partials;     // [n_wg, P] parameter-gradient partial sums, fixed point (library-owned)
     int32_t gate_P, gate_wgs;
+    int32_t *cnt;                 // reg_ego: [N] slots of the running step naming each row (library-owned, zero between steps)
 };
 // a multi-step call: nobody but this library touches E0 between its steps
 struct LoopScope {
@@ -1842,9 +1876,10 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
                      c.gate_hidden < 1 || c.gate_hidden > GATE_HMAX || c.d > 128 || !(c.pop_gate_temp > 0.f))) {
             lgcn_set_error("lgcn_ctx_create: popularity gate needs its parameter / Adam buffers, hidden sizes in 1..64, d <= 128, temperature > 0"); return 3; }
     }
+    if (c.reg_ego && (gate || smooth)) { lgcn_set_error("lgcn_ctx_create: reg_ego (upstream's L2 term) is defined for the default model only, not with the optional branches"); return 3; }
     lgcn_ctx *x = new (std::nothrow) lgcn_ctx;
     if (!x) { lgcn_set_error("out of memory"); return 4; }
-    x->c = c; x->step = 0; x->N = c.graph->n_rows;
+    x->c = c; x->step = 0; x->N = c.graph->n_rows; x->cnt = nullptr;
     x->bm_words = (x->N + 31) / 32; x->flip = 0;
     const size_t stride = (size_t)x->N * c.d * esize(c.act_dtype);
     for (int k = 0; k <= LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
@@ -1856,6 +1891,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_P = 0; x->gate_wgs = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
+    if (ok && c.reg_ego) ok = hipMalloc((void **)&x->cnt, sizeof(int32_t) * (size_t)x->N) == hipSuccess && hipMemset(x->cnt, 0, sizeof(int32_t) * (size_t)x->N) == hipSuccess;
     if (ok && x->variant) ok = hipMalloc((void **)&x->tvar, gbytes) == hipSuccess;
     if (ok && smooth) {
         const size_t wb = sizeof(uint32_t) * (size_t)((x->N - c.n_users + 31) / 32);
@@ -1890,6 +1926,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     }
     if (!ok) {
         if (x->g32) (void)hipFree(x->g32);
+        if (x->cnt) (void)hipFree(x->cnt);
         if (x->tvar) (void)hipFree(x->tvar);
         if (x->item_bitmap) (void)hipFree(x->item_bitmap);
         if (x->gate_partials) (void)hipFree(x->gate_partials);
@@ -1905,6 +1942,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
 extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->g32) (void)hipFree(ctx->g32);
+    if (ctx->cnt) (void)hipFree(ctx->cnt);
     if (ctx->tvar) (void)hipFree(ctx->tvar);
     if (ctx->item_bitmap) (void)hipFree(ctx->item_bitmap);
     if (ctx->gate_partials) (void)hipFree(ctx->gate_partials);
@@ -1951,9 +1989,11 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
 }
 
 static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
-                   int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, bool exchange, hipStream_t st) {
+                   int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, bool exchange, hipStream_t st,
+                   bool count_slots = true) {
     const lgcn_train_config &c = x->c;
     BprArgs a{};
+    a.reg_ego = c.reg_ego; a.cnt = (atomics && count_slots) ? x->cnt : nullptr;
     a.indptr = c.graph->indptr; a.indices = c.graph->indices; a.vals = c.graph->vals; a.X0 = c.E0; a.K = c.K;
     for (int k = 1; k <= x->fwd_layers; k++) a.Xl[k] = x->act[k];
     a.dense_last = c.dense_last;
@@ -2095,6 +2135,7 @@ static SlotArgs slot_args(const lgcn_ctx *x, const int32_t *users, const int32_t
     s.ent_coeff = c.item_pop ? c.gate_entropy_coeff : 0.f;
     s.blk = gathered ? dp_block_floats(x, shard) : 0;
     s.item_bitmap = (x->variant && c.i2i) ? x->item_bitmap : nullptr;
+    s.cnt = x->cnt;
     return s;
 }
 static unsigned scatter_grid(const lgcn_ctx *x, int32_t B) {      // k_scatter: one lane group of min(d, 64) lanes per slot
@@ -2144,6 +2185,7 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
         const double bc1 = 1.0 - pow(c.beta1, (double)x->step);
         const double bc2 = 1.0 - pow(c.beta2, (double)x->step);
         a.P = c.E0; a.M = c.adam_m; a.V = c.adam_v;
+        a.cnt = x->cnt; a.lam = c.decay / (float)B;
         // inside a multi-step call on replicated tables the epilogue keeps the bf16 copy of E0 current (row-sharded steps
         // update only the owned rows and convert again after the exchange)
         a.Pb = (x->e0b && x->in_loop && fused_finish) ? x->e0b : nullptr;
@@ -2274,10 +2316,10 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
     // this rank owns positions [b_off, b_off+B_local) of the global loss-term arrays; the rest must be zero
     HIP_OK(hipMemsetAsync(x->c.terms, 0, sizeof(float) * 2 * (size_t)B_global, st));
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st))) return rc;
+    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st, false))) return rc;
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B_global; s.n_users = x->c.n_users; s.N = x->N;
-    s.bitmap = x->c.bitmap + x->flip * x->bm_words;
+    s.bitmap = x->c.bitmap + x->flip * x->bm_words; s.cnt = x->cnt;
     hipLaunchKernelGGL(k_flag_rows, dim3((3 * B_global + 255) / 256), dim3(256), 0, st, s);
     HIP_OK(hipGetLastError());
     return 0;
@@ -2383,9 +2425,9 @@ static int rs_exchange(const RcclApi *api, lgcn_dp *dp, void *buf, int dtype, in
 
 // A whole data-parallel epoch from ONE host call: per global batch, part 1 -> RCCL collective on the
 // SAME stream (no host synchronisation, no Python between the kernels and the collective) -> part 2.
-extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, const int32_t *pos, const int32_t *neg,
-                                   int64_t T, int32_t B_global, int32_t reduce, const int64_t *row_ranges, float *gathered,
-                                   float *loss_out, void *stream) {
+static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                               int64_t T, int32_t B_global, int32_t reduce, const int64_t *row_ranges, float *gathered,
+                               float *loss_out, void *stream) {
     if (!x || !dp || !users || !pos || !neg || !loss_out) { lgcn_set_error("lgcn_train_epoch_dp: null argument"); return 3; }
     if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE && reduce != LGCN_DP_ROW_SHARDED) { lgcn_set_error("lgcn_train_epoch_dp: unknown reduce mode"); return 3; }
     if (reduce == LGCN_DP_ROW_SHARDED && !row_ranges) { lgcn_set_error("lgcn_train_epoch_dp: row_ranges missing"); return 3; }
@@ -2441,6 +2483,16 @@ extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *user
         }
     }
     return 0;
+}
+
+extern "C" int lgcn_train_epoch_dp(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                                   int64_t T, int32_t B_global, int32_t reduce, const int64_t *row_ranges, float *gathered,
+                                   float *loss_out, void *stream) {
+    const int rc = train_epoch_dp_impl(x, dp, users, pos, neg, T, B_global, reduce, row_ranges, gathered, loss_out, stream);
+    // a rank that leaves the loop early never reaches its next collective: release the loopback ranks waiting for it
+    // (RCCL has its own abort / timeout machinery)
+    if (rc && dp && dp->loopback) lgcn_dp_loopback_abort(dp);
+    return rc;
 }
 
 extern "C" int lgcn_ctx_check(lgcn_ctx *x, void *stream) {

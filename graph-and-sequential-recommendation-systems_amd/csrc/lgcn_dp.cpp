@@ -96,5 +96,12 @@ extern "C" void lgcn_dp_destroy(lgcn_dp *dp) {
     delete dp;
 }
 
+extern "C" int lgcn_dp_allreduce_sum_f32(lgcn_dp *dp, float *buf, int64_t n, void *stream) {
+    if (!dp || !dp->api || !buf || n <= 0) { lgcn_set_error("lgcn_dp_allreduce_sum_f32: invalid argument"); return 3; }
+    ncclResult_t r = dp->api->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, dp->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) { lgcn_set_error("ncclAllReduce failed"); return 11; }
+    return 0;
+}
+
 extern "C" int lgcn_dp_world(const lgcn_dp *dp) { return dp ? dp->world : 0; }
 extern "C" int lgcn_dp_rank(const lgcn_dp *dp) { return dp ? dp->rank : -1; }

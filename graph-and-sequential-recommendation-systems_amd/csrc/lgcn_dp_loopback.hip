@@ -23,7 +23,7 @@ struct Op { const void *send; void *recv; size_t bytes; int root; };
 struct Group {
     int world;
     std::mutex mu; std::condition_variable cv;
-    int arrived = 0; long generation = 0; bool failed = false;
+    int arrived = 0; long generation = 0; bool failed = false, aborted = false;
     std::vector<std::vector<Op>> ops;          // per rank: the ops of the open group (or the single op of a collective)
     std::vector<void *> scratch; std::vector<size_t> scratch_bytes;     // per rank: all-reduce staging
     int refs;
@@ -32,10 +32,16 @@ struct Group {
     bool barrier(bool ok = true) {
         std::unique_lock<std::mutex> lk(mu);
         if (!ok) failed = true;
+        if (aborted) return false;                 // a rank has left the epoch: nobody waits for it again
         const long gen = generation;
         if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else cv.wait(lk, [&] { return generation != gen || aborted; });
         return !failed;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -168,6 +174,8 @@ extern "C" int lgcn_dp_init_loopback(int world, lgcn_dp **out) {
     }
     return 0;
 }
+
+void lgcn_dp_loopback_abort(lgcn_dp *dp) { reinterpret_cast<Loop *>(dp->comm)->g->abort(); }
 
 // called by lgcn_dp_destroy for a loopback communicator
 void lgcn_dp_loopback_release(lgcn_dp *dp) {

@@ -29,4 +29,5 @@ struct lgcn_dp {
     bool loopback;
 };
 void lgcn_dp_loopback_release(lgcn_dp *dp);      // lgcn_dp_loopback.hip
+void lgcn_dp_loopback_abort(lgcn_dp *dp);        // a rank failed outside a collective: wake every waiter, all later collectives fail
 #endif

@@ -104,14 +104,20 @@ struct SegArgs {
 
 __global__ void __launch_bounds__(256) k_samp_pairs(SegArgs g) {
     const SampleArgs &a = g.a;
-    const long long t0 = g.st->t_begin;
-    if (t0 >= a.T || g.st->fail) return;
-    const long long t1 = min((long long)a.T, t0 + g.seg), din = g.st->delta;
-    const long long pbase = 2 * t0 + din + 1, plast = 2 * (t1 - 1) + din + SAMP_DMAX + 1;
     const int tid = threadIdx.x;
-    const long long p = pbase + (long long)blockIdx.x * 256 + tid;
     __shared__ int cnt[256];
     __shared__ int total;
+    __shared__ long long s_t0, s_din;
+    __shared__ int s_skip;
+    // the state is read ONCE per workgroup: another workgroup of this launch may raise `fail` at any time, and a
+    // workgroup whose threads saw different values would leave cnt[] half written
+    if (tid == 0) { s_t0 = g.st->t_begin; s_din = g.st->delta; s_skip = g.st->fail != 0; }
+    __syncthreads();
+    const long long t0 = s_t0;
+    if (t0 >= a.T || s_skip) return;
+    const long long t1 = min((long long)a.T, t0 + g.seg), din = s_din;
+    const long long pbase = 2 * t0 + din + 1, plast = 2 * (t1 - 1) + din + SAMP_DMAX + 1;
+    const long long p = pbase + (long long)blockIdx.x * 256 + tid;
     int c = 0;
     int ulo = 0, uhi = -1, cand = 0;
     if (p <= plast && p < a.n_draws) {
@@ -240,8 +246,17 @@ __global__ void __launch_bounds__(256) k_samp_events(SegArgs g, int nblocks) {
         __syncthreads();
     }
     if (tid == 0) {
-        st->seg_t0 = t0; st->seg_t1 = seg_end; st->seg_delta = din; st->n_events = nev;
-        st->t_begin = seg_end; st->delta = s_d;
+        // Every draw the triplets [t0, seg_end) read lies below 2 * seg_end + delta_out.  k_samp_pairs skipped the positions
+        // past the end of the expanded stream (they count as accepted) and k_samp_emit reads R unchecked, so a segment that
+        // reaches past the stream is DISCARDED: its state stays where it was, `fail` is raised and k_sample -- which checks
+        // every window against n_draws -- finishes from there and reports the exhausted stream (rc 5) if it really is.
+        if (2 * seg_end + s_d > a.n_draws) {
+            atomicExch(&st->fail, 1);
+            st->seg_t0 = st->seg_t1 = 0; st->n_events = 0;
+        } else {
+            st->seg_t0 = t0; st->seg_t1 = seg_end; st->seg_delta = din; st->n_events = nev;
+            st->t_begin = seg_end; st->delta = s_d;
+        }
     }
 }
 
@@ -331,6 +346,16 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) k_sample(SampleArgs a, const S
     if (tid == 0) { a.result[0] = 2 * a.T + s_delta; a.result[1] = s_fail; }
 }
 
+// Stream margin: draws expanded beyond the 2 per triplet every epoch needs = T / g_margin_div + g_margin_fixed (2 % + slack).
+// lgcn_sampler_test_margin is a TEST HOOK (tests/test_gpu_parity.py drives the segment path into the end of the stream
+// with it); values <= 0 restore the defaults.
+static int64_t g_margin_div = 50, g_margin_fixed = 65536;
+extern "C" void lgcn_sampler_test_margin(int64_t divisor, int64_t fixed) {
+    g_margin_div = divisor > 0 ? divisor : 50;
+    g_margin_fixed = fixed > 0 ? fixed : 65536;
+}
+static inline int64_t stream_draws(int64_t T) { return 2 * T + T / g_margin_div + g_margin_fixed; }
+
 static inline int64_t seg_pair_blocks() { return (2 * (int64_t)SAMP_SEG_MAX + SAMP_DMAX) / 256 + 2; }
 static inline int64_t seg_workspace_bytes() {
     return 256 /* state */ + seg_pair_blocks() * (SAMP_PCAP * 8 + 4) + SAMP_EV_MAX * (int64_t)sizeof(SampEvent) + 256;
@@ -339,7 +364,7 @@ static inline int64_t seg_workspace_bytes() {
 extern "C" int64_t lgcn_sample_negative_device_workspace(int user_num, int64_t train_num) {
     if (user_num <= 0 || train_num < 0) return 0;
     const int64_t T = (int64_t)user_num * (train_num / user_num);
-    const int64_t draws = 2 * T + T / 50 + 65536;                    // 2 % + slack for rejections
+    const int64_t draws = stream_draws(T);
     const int64_t nblocks = (draws + GLIBC_BLOCK - 1) / GLIBC_BLOCK;
     return nblocks * GLIBC_BLOCK * 4 + nblocks * 31 * 4 + 256 + seg_workspace_bytes();
 }
@@ -359,7 +384,7 @@ extern "C" int lgcn_sample_negative_device(int user_num, int item_num, int64_t t
         if (deg >= item_num) { lgcn_set_error("sample_negative: a user is positive on every item (rejection loop would not end)"); return 2; }
     }
     if (workspace_bytes < lgcn_sample_negative_device_workspace(user_num, train_num)) { lgcn_set_error("sample_negative_device: workspace too small"); return 3; }
-    const int64_t draws = 2 * T + T / 50 + 65536;
+    const int64_t draws = stream_draws(T);
     const int64_t nblocks = (draws + GLIBC_BLOCK - 1) / GLIBC_BLOCK;
     hipStream_t st = (hipStream_t)stream;
     uint32_t *R = (uint32_t *)workspace;

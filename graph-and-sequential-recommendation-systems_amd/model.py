@@ -318,6 +318,10 @@ class LightGCN(nn.Module):
         cfg.decay = float(self.config.get('decay', 1e-4))
         cfg.lr = float(self.config.get('lr', 1e-3))
         cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.999, 1e-8
+        cfg.reg_ego = 1 if str(self.config.get('reg_rows', 'propagated')) == 'ego' else 0
+        if cfg.reg_ego and variants:
+            raise _lib.LgcnError("--reg_rows ego (upstream LightGCN's L2 term) is defined for the default model, not with "
+                                 "--use_pop_gate / --use_item_item")
         cfg.xcd_remap = int(self.config.get('xcd_remap', 1))
         cfg.dense_last = int(dense_last)
         cfg.hub_nnz = int(self.config.get('hub_nnz', 0))          # 0: library default; < 0: off
@@ -477,7 +481,11 @@ class LightGCN(nn.Module):
         pos_scores = torch.sum(u * pos_e, dim=1)
         neg_scores = torch.sum(u * neg_e, dim=1)
         bpr = -torch.mean(F.logsigmoid(pos_scores - neg_scores))
-        reg_loss = (0.5 * (u.norm(2).pow(2) + pos_e.norm(2).pow(2) + neg_e.norm(2).pow(2))) / float(u.shape[0])
+        if str(self.config.get('reg_rows', 'propagated')) == 'ego':      # upstream LightGCN: userEmb0 / posEmb0 / negEmb0
+            u0, p0, n0 = self.embedding_user.weight[users.long()], self.embedding_item.weight[pos.long()], self.embedding_item.weight[neg.long()]
+            reg_loss = (0.5 * (u0.norm(2).pow(2) + p0.norm(2).pow(2) + n0.norm(2).pow(2))) / float(u.shape[0])
+        else:
+            reg_loss = (0.5 * (u.norm(2).pow(2) + pos_e.norm(2).pow(2) + neg_e.norm(2).pow(2))) / float(u.shape[0])
         loss = bpr
         if self.use_pop_gate and hasattr(self, "_last_item_gate"):
             gates = torch.cat([self._last_item_gate[pos], self._last_item_gate[neg]], dim=0)

@@ -182,6 +182,19 @@ class DataParallelBPR:
                           "using torch.distributed collectives per step", file=sys.stderr)
         return self._comm_ok
 
+    def ranks_observed(self):
+        """How many ranks the collectives of the data path actually span: a SUM all-reduce of 1.0 per rank through the
+        library's own RCCL communicator (the one lgcn_train_epoch_dp issues its collectives on), or -- when the ranks agreed
+        to fall back -- through torch.distributed.  -> (count, 'library RCCL communicator' | 'torch.distributed')."""
+        dev = self.model._table.device
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        if dev.type == 'cuda' and self._own_communicator_ok():
+            _lib.check(_lib.load().lgcn_dp_allreduce_sum_f32(self._communicator(), _lib.tp(one), 1, _lib.current_stream()),
+                       "lgcn_dp_allreduce_sum_f32")
+            return int(round(float(one.item()))), "library RCCL communicator"
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+        return int(round(float(one.item()))), "torch.distributed"
+
     def close(self):
         if self._comm is not None:
             _lib.load().lgcn_dp_destroy(self._comm)

@@ -82,6 +82,10 @@ def build_parser():
     p.add_argument('--eval_fused', type=int, default=1,
                    help='NEW: 1 = Procedure.Test through the fused HIP kernels (MFMA scores + mask + top-k, metrics on device); '
                         '0 = torch matmul/topk harness')
+    p.add_argument('--reg_rows', type=str, default='propagated', choices=['propagated', 'ego'],
+                   help="NEW: rows the L2 term of bpr_loss is taken on. 'propagated' (default) = this reference (model.py:173: the "
+                        "propagated rows of the batch); 'ego' = upstream LightGCN (userEmb0 / posEmb0 / negEmb0, the embedding "
+                        "tables' own rows) -- the loss behind the recorded 1000-epoch run and the README table the reference keeps")
     p.add_argument('--data_path', type=str, default=None,
                    help='NEW: directory that holds <dataset>/train.txt (default: <root>/data)')
     return p

@@ -99,6 +99,7 @@ def configure(argv=None):
     config['xcd_remap'] = args.xcd_remap
     config['row_order'] = args.row_order
     config['prefetch_epoch'] = args.prefetch_epoch
+    config['reg_rows'] = args.reg_rows
     config['eval_fused'] = args.eval_fused
     config['gpu_sampler'] = args.gpu_sampler
     config['dense_last'] = args.dense_last

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 9
+#define LGCN_ABI_VERSION 10
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -67,6 +67,10 @@ int64_t lgcn_sample_negative_device_workspace(int user_num, int64_t train_num);
 int lgcn_sample_negative_device(int user_num, int item_num, int64_t train_num,
                                 const int64_t *h_indptr, const int64_t *d_indptr, const int32_t *d_indices,
                                 int32_t *d_S, void *workspace, int64_t workspace_bytes, void *stream);
+/* TEST HOOK: the device sampler expands 2 draws per triplet + T / divisor + fixed more (default 50, 65536) and
+ * returns 5 -- host generator untouched -- when an epoch's rejections need more.  A test makes the margin small to
+ * drive the segmented path into the end of the stream; values <= 0 restore the defaults.  Affects the workspace size. */
+void lgcn_sampler_test_margin(int64_t divisor, int64_t fixed);
 
 /* numpy legacy global RandomState stream (MT19937), used by the reference for
  * the fallback sampler and the epoch shuffle.                                 */
@@ -200,6 +204,13 @@ typedef struct {
     int32_t gate_hidden;        /* Hg */
     float gate_entropy_coeff;
     float pop_gate_temp;
+    /* Which rows the L2 term of the loss is taken on.  0 (default) = the reference: the PROPAGATED rows of the batch
+     * (model.py:173: u.norm(2), pos_e.norm(2), neg_e.norm(2) of getEmbedding's outputs).  1 = UPSTREAM LightGCN, the code the
+     * reference forked and whose recorded 1000-epoch run / README table it keeps (code/runs/07-10-17h52m32s--lgn,
+     * LightGCN_work/README.md:88-95): the embedding tables' OWN rows of the batch (userEmb0 / posEmb0 / negEmb0), whose
+     * gradient decay/B * count(row) * E0[row] does not pass through the propagation -- the Adam epilogue adds it from a
+     * per-row slot count.  Not available together with the optional branches.                                        */
+    int32_t reg_ego;
 } lgcn_train_config;
 
 /* Besides the caller's workspace the context owns device allocations made here with hipMalloc and released by
@@ -310,6 +321,9 @@ int lgcn_dp_init(const void *id128, int world, int rank, lgcn_dp **out);   /* on
  * lgcn_train_epoch_dp with its own context, tables, stream and communicator.  Synchronous by construction. */
 int lgcn_dp_init_loopback(int world, lgcn_dp **out);
 void lgcn_dp_destroy(lgcn_dp *dp);
+/* In-place SUM all-reduce of n device floats over the communicator, on `stream` (no host sync).  bench.py counts the ranks
+ * RCCL itself sees with it (an all-reduce of 1.0 per rank), independent of torch.distributed's WORLD_SIZE. */
+int lgcn_dp_allreduce_sum_f32(lgcn_dp *dp, float *buf, int64_t n, void *stream);
 int lgcn_dp_world(const lgcn_dp *dp);
 int lgcn_dp_rank(const lgcn_dp *dp);
 /* A whole data-parallel epoch in one host call: the loop of main.py:223-225 over ceil(T/B_global)

@@ -22,7 +22,9 @@ import torch.nn.functional as F
 
 
 class EagerTrainer:
-    def __init__(self, n_users, indptr, indices, vals, e0, K, decay=1e-4, lr=1e-3, threads=None):
+    def __init__(self, n_users, indptr, indices, vals, e0, K, decay=1e-4, lr=1e-3, threads=None, reg_rows='propagated'):
+        assert reg_rows in ('propagated', 'ego')      # 'ego': upstream LightGCN's L2 term (userEmb0 / posEmb0 / negEmb0), see lgcn_oracle.c orc_bpr_ego
+        self.reg_rows = reg_rows
         if threads:
             torch.set_num_threads(int(threads))
         N = len(indptr) - 1
@@ -50,7 +52,11 @@ class EagerTrainer:
         all_users, all_items = self.computer()
         u, p, n = all_users[users], all_items[pos], all_items[neg]
         bpr = -torch.mean(F.logsigmoid(torch.sum(u * p, dim=1) - torch.sum(u * n, dim=1)))
-        reg = 0.5 * (u.norm(2).pow(2) + p.norm(2).pow(2) + n.norm(2).pow(2)) / float(len(users))
+        if self.reg_rows == 'ego':
+            u0, p0, n0 = self.user_w[users], self.item_w[pos], self.item_w[neg]
+            reg = 0.5 * (u0.norm(2).pow(2) + p0.norm(2).pow(2) + n0.norm(2).pow(2)) / float(len(users))
+        else:
+            reg = 0.5 * (u.norm(2).pow(2) + p.norm(2).pow(2) + n.norm(2).pow(2)) / float(len(users))
         loss = bpr + self.decay * reg
         self.opt.zero_grad()
         loss.backward()

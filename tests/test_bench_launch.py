@@ -28,6 +28,8 @@ def test_bench_self_launches_two_ranks():
     assert j["steps"] == 7 and j["warmup"] == 2 and j["workload"] == "amazon-book-shaped"
     # default = strong scaling: the reference's ONE global batch of 2048 is sharded
     assert j["scaling"] == "strong" and j["global_batch"] == 2048
+    # the ranks the collectives really span (an all-reduce of 1 per rank), not WORLD_SIZE; the 400-step steady-state region
+    assert j["rccl_ranks_observed"] == 2 and j["steady_state_steps"] == 400
 
 
 def test_bench_weak_scaling_flag():
@@ -42,6 +44,10 @@ def test_bench_single_rank_and_mismatch():
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["workload"] == "gowalla" and j["steps"] == 400 and j["warmup"] == 20
+    # N = 1: "scaling" is the configured mode (config.scaling_mode says the same), one rank observed, and the line carries
+    # the end-to-end epoch rate and the 10-epoch quality object next to roofline / cpu_baseline
+    assert j["scaling"] == "strong" and j["rccl_ranks_observed"] == 1
+    assert {"end_to_end_epoch", "quality", "roofline", "cpu_baseline"} <= set(j["extra_objects"])
     # started by an external launcher with a different world size: refuse, do not guess
     p = _run(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

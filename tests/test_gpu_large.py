@@ -197,6 +197,69 @@ def test_c5_full_shape(pkg, oracle):
         assert not bool(st['G64'].any())                             # the step left its accumulator clean
         return rows, loss, m._table.detach()[chk_t].clone(), m._table.detach()[sample_t].clone()
 
+    # ---- the BACKWARD of the step against the oracle-verified FORWARD (adjoint identity), at full size.
+    # The step's gradient is g = M G with M = (I + A + A^2 + A^3) / 4 (symmetric) and G = d loss / d(propagated rows), non-zero
+    # on the <= 3B batch rows.  For any y:  <y, g> = <M y, G>.  Left: g as the step's own kernels produced it (k_triplet's
+    # fixed-point scatter, the SPARSE|ADDG, ADDG and ADDG|ADAM launches of k_spmm<256,..,BIG> with the hub plan) -- read from
+    # Adam's first moment, which after the FIRST step from zero state holds fl((1 - beta1) * g) exactly (exp_avg.lerp_).
+    # Right: M y = lgcn_propagate_mean on y in fp32 -- the forward this test has just checked layer by layer against the oracle --
+    # and G = oracle.bpr (model.py:162-183 + its analytic gradient) on the propagated batch rows.  Tolerance: the two sides are
+    # sums of ~1e9 fp32 products whose terms carry the rounding of 2K - 1 launches (rows of up to 800 000 terms); it is stated
+    # against the sum of ABSOLUTE values  Aabs = <M |y|, |G|>  (computed with the same operator): 64 * 2^-24 * Aabs in fp32;
+    # with bf16 activation storage the K - 1 stored backward intermediates are each rounded to 8 significant bits
+    # (2^-9 relative), so + (K - 1) * 2^-9 * Aabs there.  A dropped or doubled term (a layer, the hub rows, a slot block)
+    # changes the left side by O(Aabs / (K + 1)).
+    batch_rows = np.unique(np.concatenate([users.astype(np.int64), n_users + p.cpu().numpy().astype(np.int64), n_users + n.cpu().numpy().astype(np.int64)]))
+    batch_rows_t = torch.from_numpy(batch_rows).to(DEV)
+    n_users_c = int((batch_rows < n_users).sum())
+    users_c = np.searchsorted(batch_rows, users.astype(np.int64))
+    pos_c = np.searchsorted(batch_rows, n_users + p.cpu().numpy().astype(np.int64)) - n_users_c
+    neg_c = np.searchsorted(batch_rows, n_users + n.cpu().numpy().astype(np.int64)) - n_users_c
+    hubs_t = torch.from_numpy(hubs).to(DEV)
+
+    def mean_propagate(y):
+        work = torch.empty(K - 1, N, d, device=DEV)
+        out = torch.empty(N, d, device=DEV)
+        L.check(lib.lgcn_propagate_mean(g.handle, L.tp(y), K, d, 0, L.tp(work), L.tp(out), L.current_stream()), "mean")
+        del work
+        return out
+
+    def dot64(a, b):
+        tot = 0.0
+        for r0 in range(0, N, 1 << 20):
+            tot += float((a[r0:r0 + (1 << 20)].double() * b[r0:r0 + (1 << 20)].double()).sum())
+        return tot
+
+    def adjoint_check(act, table_rows):
+        st = m._dev
+        assert int(lib.lgcn_ctx_get_step(st['ctx'])) == 1
+        w1 = np.float32(1.0 - 0.9)                                     # what the Adam epilogue multiplies g by (a.w1)
+        gm = st['adam_m']                                              # fl(w1 * g), [N, d]
+        bpr_o, reg_o, G_c = oracle.bpr(table_rows, n_users_c, users_c, pos_c, neg_c, float(w.config['decay']))
+        assert abs(bpr_o - bpr_ref) < 2e-6 and abs(reg_o - reg_ref) < 2e-6 * max(1.0, reg_ref)
+        G_t = torch.from_numpy(G_c).to(DEV).double()
+        gen = torch.Generator(device=DEV); gen.manual_seed(11)
+        y = torch.randn(N, d, device=DEV, generator=gen)
+        cases = [("all rows", None), ("rows outside the batch (propagation terms only)", "off_batch"), ("hub rows only", "hubs")]
+        for what, mask in cases:
+            if mask == "off_batch":
+                y[batch_rows_t] = 0.0
+            elif mask == "hubs":
+                keep = y[hubs_t].clone(); y.zero_(); y[hubs_t] = keep
+            lhs = dot64(y, gm) / float(w1)
+            My = mean_propagate(y)
+            rhs = float((My[batch_rows_t].double() * G_t).sum())
+            del My
+            ya = y.abs()
+            Mya = mean_propagate(ya)
+            aabs = float((Mya[batch_rows_t].double() * G_t.abs()).sum())
+            del Mya, ya
+            tol = 64 * EPS32 * aabs + (0.0 if act == "fp32" else (K - 1) * 2.0 ** -9 * aabs)
+            print(f"[c5 adjoint {act}: {what}] <y,g> {lhs:.9e}  <My,G> {rhs:.9e}  diff {abs(lhs - rhs):.3e}  "
+                  f"Aabs {aabs:.3e}  diff/Aabs {abs(lhs - rhs) / aabs:.3e}  tol/Aabs {tol / aabs:.3e}")
+            assert aabs > 0 and abs(lhs - rhs) <= tol, (act, what, lhs, rhs, aabs, tol)
+        del y
+
     for act in ("fp32", "bf16"):
         m.config['act_dtype'] = act
         with torch.no_grad():
@@ -204,6 +267,7 @@ def test_c5_full_shape(pkg, oracle):
             m.invalidate_cache()
             table = m._propagate_dense()                              # the rows bpr_loss gathers, in this storage mode
         bpr_ref, reg_ref = loss_from(table)
+        table_rows = table[batch_rows_t].cpu().numpy()                    # the <= 3B propagated rows the loss reads, in this storage mode
         del table
         rows_on, loss_on, chk_on, smp_on = one_step(act, 0)              # library default = production threshold 131 072
         assert rows_on == len(hubs)
@@ -214,6 +278,7 @@ def test_c5_full_shape(pkg, oracle):
         assert int((delta.amax(1) > 0).sum()) > 3 * B                     # and reaches far more rows than the batch names
         assert float(delta[n_users + top_item].max()) > 0
         del delta
+        adjoint_check(act, table_rows)
         rows_on2, loss_on2, chk_on2, smp_on2 = one_step(act, 0)            # the same step again: bit for bit (fixed-point scatter)
         assert rows_on2 == rows_on and np.array_equal(loss_on, loss_on2) and torch.equal(chk_on, chk_on2) and torch.equal(smp_on, smp_on2)
         rows_off, loss_off, chk_off, smp_off = one_step(act, -1)

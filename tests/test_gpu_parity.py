@@ -88,7 +88,7 @@ def test_spmm_edge_cases(pkg, oracle):
                 torch.zeros(1, device=DEV))                                               # non-monotone indptr
 
 
-def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="cocluster"):
+def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="cocluster", reg_rows="propagated"):
     d = os.path.join(str(tmp_path), g.name + act_dtype)
     os.makedirs(d, exist_ok=True)
     for f in ("train.txt", "test.txt"):
@@ -97,7 +97,8 @@ def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="c
     w.configure([])
     w.dataset = g.name
     w.config.update({'lightGCN_n_layers': K or g.K, 'latent_dim_rec': g.d, 'bpr_batch_size': B or g.B,
-                     'act_dtype': act_dtype, 'decay': g.meta["decay"], 'lr': g.meta["lr"], 'row_order': row_order})
+                     'act_dtype': act_dtype, 'decay': g.meta["decay"], 'lr': g.meta["lr"], 'row_order': row_order,
+                     'reg_rows': reg_rows})
     w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
     ds = pkg.dataloader.Loader(w.config, path=d)
     pkg.sampling.seed(w.seed)
@@ -158,6 +159,111 @@ def test_fused_step_vs_oracle(pkg, oracle, tiny, tmp_path, K):
     # workspace is clean again after the step
     assert int(st['G64'].abs().sum()) == 0          # (the row bitmaps alternate; the stale one is zeroed by the next step)
     m.check_device_errors()
+
+
+@pytest.mark.parametrize("dense_last", ["0", "1"])
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_upstream_loss_fused_step_vs_oracle(pkg, oracle, tiny, tmp_path, K, dense_last):
+    """--reg_rows ego: UPSTREAM LightGCN's bpr_loss (L2 term on the embedding tables' own rows of the batch -- the loss behind the
+    recorded 1000-epoch run and README table the reference keeps; this fork moved the term to the propagated rows, model.py:173).
+    In the fused step the term's gradient decay/B * count(row) * E0[row] bypasses the propagation: k_triplet counts the slots
+    per row, the Adam epilogue adds count * lam * P[row].  Three steps (duplicated users / items, pos-neg collisions, B = 1) vs
+    oracle.Trainer(reg_rows='ego') -- whose gradient algebra test_oracle checks against torch autograd -- for K = 1 (sparse +
+    Adam in one launch), 2, 3 and both last-layer forms; and the unfused autograd path of model.bpr_loss on the same batch."""
+    g = tiny
+    ds, m = _make_model(pkg, g, tmp_path, K=K, reg_rows="ego")
+    m.config['dense_last'] = dense_last
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    tr = oracle.Trainer(g.n_users, *A, g.e0(), K, g.meta["decay"], g.meta["lr"], reg_rows="ego")
+    rng = np.random.Generator(np.random.PCG64(100 + K))
+    u = rng.integers(0, g.n_users, 64); p = rng.integers(0, g.m_items, 64); n = rng.integers(0, g.m_items, 64)
+    u[:8] = u[0]; p[:8] = p[0]; n[8:12] = p[0]
+    # unfused: model.bpr_loss + autograd (the reference's call shape) against the oracle's loss / reg of the same batch
+    E = oracle.propagate(*A, g.e0(), K)
+    l_o, r_o, G_o, Gego_o = oracle.bpr_ego(E, g.e0(), g.n_users, u, p, n, g.meta["decay"])
+    m.train()
+    loss, reg = m.bpr_loss(_dev(u), _dev(p), _dev(n))
+    assert abs(float(loss) - l_o) < 2e-6 and abs(float(reg) - r_o) < 2e-6 * max(1.0, r_o)
+    (loss + g.meta["decay"] * reg).backward()
+    grad = torch.cat([m.embedding_user.weight.grad, m.embedding_item.weight.grad]).cpu().numpy()
+    want = oracle.propagate_bwd(*A, G_o, K) + Gego_o
+    np.testing.assert_allclose(grad, want, rtol=2e-4, atol=2e-9)
+    m.zero_grad(set_to_none=True)
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    for step in range(3):
+        nb = [64, 17, 1][step]
+        if step:
+            u = rng.integers(0, g.n_users, nb); p = rng.integers(0, g.m_items, nb); n = rng.integers(0, g.m_items, nb)
+        l_ref = tr.stageOne(u, p, n)
+        l_got = bpr.stageOne(_dev(u), _dev(p), _dev(n))
+        assert abs(l_got - l_ref) < 3e-6, (step, l_got, l_ref)
+        np.testing.assert_allclose(m._table.cpu().numpy(), tr.e0, rtol=0, atol=3e-6)
+    st = m._dev
+    assert int(st['G64'].abs().sum()) == 0
+    # and it IS another loss: the fork's step from the same start lands elsewhere
+    t2 = oracle.Trainer(g.n_users, *A, g.e0(), K, g.meta["decay"], g.meta["lr"])
+    t3 = oracle.Trainer(g.n_users, *A, g.e0(), K, g.meta["decay"], g.meta["lr"], reg_rows="ego")
+    t2.stageOne(u, p, n); t3.stageOne(u, p, n)
+    assert np.abs(t2.e0 - t3.e0).max() > 1e-7
+    m.check_device_errors()
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense", "row_sharded"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_upstream_loss_dp_epoch_loopback(pkg, tiny, tmp_path, world, mode):
+    """--reg_rows ego under data parallelism, the C loop at world 2 / 3 through the loopback communicator in all three exchange
+    modes: the per-row slot counts are integers (own shard in part 1 + the other ranks' in k_scatter; the whole batch in
+    k_flag_rows for the dense form; k_scatter alone for row-sharded), so every rank ends bit for bit where the single-GPU
+    epoch ends -- and three epochs in a row leave the counts clean (a stale count would change the next epoch)."""
+    import threading
+    g = tiny
+    rng = np.random.Generator(np.random.PCG64(23 * world + len(mode)))
+    B = 48
+    T = 3 * B + 1
+    u = rng.integers(0, g.n_users, T); p = rng.integers(0, g.m_items, T); n = rng.integers(0, g.m_items, T)
+    u[5] = u[40]; p[7] = p[30]; n[9] = p[30]
+    U, P, Nn = (_dev(x, torch.int32) for x in (u, p, n))
+    ds, ref = _make_model(pkg, g, tmp_path, B=B, reg_rows="ego")
+    L, lib = pkg._lib, pkg._lib.load()
+    models = [_make_model(pkg, g, tmp_path, B=B, reg_rows="ego")[1] for _ in range(world)]
+    par = pkg.parallel
+    ranges = par.row_ranges(models[0]._adj.indptr, models[0].n_users, world) if mode == "row_sharded" else None
+    states = [mm._state(max_batch=B, need_ctx=True, dp_world=world,
+                        row_subset=par.owned_rows(ranges, r) if ranges is not None else None) for r, mm in enumerate(models)]
+    comms = (C.c_void_p * world)()
+    L.check(lib.lgcn_dp_init_loopback(world, comms), "loopback")
+    code = {"rows": 0, "dense": 1, "row_sharded": 2}[mode]
+    steps = (T + B - 1) // B
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    gathered = [torch.empty(world * par.block_numel(B, world, g.d), device=DEV) for _ in range(world)]
+    losses = [torch.empty(steps, 3, device=DEV) for _ in range(world)]
+    rr = np.ascontiguousarray(ranges, np.int64) if ranges is not None else None
+    for epoch in range(3):
+        want_loss = ref.fused_epoch(U, P, Nn, B).cpu().numpy()
+        want = ref._table.cpu().numpy().view(np.uint32)
+        torch.cuda.synchronize()
+        rcs, errs = [None] * world, [None] * world
+
+        def rank_main(r):
+            rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, code,
+                                             L.npp(rr) if rr is not None else None, L.tp(gathered[r]), L.tp(losses[r]),
+                                             C.c_void_p(streams[r].cuda_stream))
+            if rcs[r]:
+                errs[r] = lib.lgcn_last_error()
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a rank did not come back from lgcn_train_epoch_dp"
+        torch.cuda.synchronize()
+        assert rcs == [0] * world, (rcs, errs)
+        for r, mm in enumerate(models):
+            assert np.array_equal(losses[r].cpu().numpy(), want_loss), (mode, world, r, epoch)
+            assert np.array_equal(mm._table.cpu().numpy().view(np.uint32), want), (mode, world, r, epoch)
+            mm.check_device_errors()
+    for r in range(world):
+        lib.lgcn_dp_destroy(comms[r])
 
 
 def test_epochs_tiny_vs_golden(pkg, tiny, tmp_path):
@@ -1308,6 +1414,49 @@ def test_gpu_sampler_segments_heavy_tail_bit_exact(pkg):
         bad = np.flatnonzero((w_ != g_).any(axis=1))
         assert g_.dtype == np.int32 and bad.size == 0, (e, bad[:5], w_[bad[:3]], g_[bad[:3]])
     assert tail_host == tail_dev
+
+
+def test_gpu_sampler_segments_reach_the_end_of_the_stream(pkg):
+    """a MID-density dataset (2.5 % of the items positive per user: the segments complete, none overflows a
+    capacity) whose rejections need more draws than the stream margin holds.  The segment kernels skip positions past the
+    expanded stream and emit without bound checks, so before the fix the call returned 0 with garbage in the last triplets
+    and moved the host generator by a wrong count.  With the margin made small through the test hook, EVERY margin must
+    end in one of two ways: rc 5 with the host generator untouched, or rc 0 with the host sampler's rows bit for bit and
+    the generator at the host's position -- and both outcomes must occur over the sweep."""
+    S = pkg.sampling
+    lib = pkg._lib.load()
+    rng = np.random.Generator(np.random.PCG64(77))
+    n_users, m_items, deg = 4000, 2000, 50
+    rows = [np.sort(rng.choice(m_items, size=deg, replace=False)).astype(np.int32) for _ in range(n_users)]
+    indptr = (np.arange(n_users + 1, dtype=np.int64) * deg)
+    indices = np.concatenate(rows)
+    train_num = n_users * deg
+    S.seed(5)
+    want = S.sample_negative(n_users, m_items, train_num, (indptr, indices), 1)
+    tail_host = [S.randint(1 << 20) for _ in range(4)]
+    outcomes = []
+    try:
+        for fixed in (1, 1500, 3000, 4000, 4600, 5000, 5400, 6000, 8000, 12000, 20000):
+            lib.lgcn_sampler_test_margin(1 << 40, fixed)
+            S._DEVICE_CSR.clear()
+            S.seed(5)
+            try:
+                got = S.sample_negative_device(n_users, m_items, train_num, (indptr, indices), DEV).cpu().numpy()
+            except pkg._lib.LgcnError as e:
+                assert "(rc=5)" in str(e), str(e)
+                # the host generator has not moved: the host sampler now draws the epoch the reference draws
+                assert np.array_equal(S.sample_negative(n_users, m_items, train_num, (indptr, indices), 1), want), fixed
+                outcomes.append(5)
+                continue
+            bad = np.flatnonzero((want != got).any(axis=1))
+            assert bad.size == 0, (fixed, bad[:5], want[bad[:3]], got[bad[:3]])
+            assert [S.randint(1 << 20) for _ in range(4)] == tail_host, fixed
+            outcomes.append(0)
+    finally:
+        lib.lgcn_sampler_test_margin(0, 0)
+        S._DEVICE_CSR.clear()
+    assert 5 in outcomes and 0 in outcomes, outcomes
+    assert outcomes == sorted(outcomes, reverse=True), outcomes        # small margins fail, large ones pass
 
 
 def test_gpu_sampler_margin_falls_back_to_host(pkg, tmp_path):
