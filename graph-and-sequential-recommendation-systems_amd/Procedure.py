@@ -175,6 +175,17 @@ class _EvalIndex:
         self.train_idx32 = self.train_idx.to(torch.int32)
         order = np.lexsort((items, np.repeat(np.arange(len(self.users)), lens)))
         self.test_sorted32 = torch.from_numpy(items[order].astype(np.int32)).to(dev)
+        # the train-positive masks of the evaluated users, tile-major (lgcn_eval_build_masks): built once per dataset, so
+        # the item sweep of every Test holds no data-dependent load.  Only while they stay small (<= 1 GiB); else the sweep
+        # walks the train CSR with a cursor as before.
+        self.masks = None
+        if torch.device(dev).type == 'cuda' and len(self.users):
+            lib = _lib.load()
+            words = int(lib.lgcn_eval_mask_words(int(dataset.m_items), len(self.users)))
+            if 0 < words <= (1 << 28) and int(world.config.get('eval_masks', 1)):
+                self.masks = torch.empty(words, dtype=torch.int32, device=dev)
+                _lib.check(lib.lgcn_eval_build_masks(_lib.tp(self.users32), len(self.users), _lib.tp(self.train_ptr), _lib.tp(self.train_idx32),
+                                                     int(dataset.m_items), _lib.tp(self.masks), _lib.current_stream()), "lgcn_eval_build_masks")
 
     @staticmethod
     def _expand(ptr, rows):
@@ -194,9 +205,10 @@ def _test_fused(Recmodel, ev, max_K):
     n = len(ev.users)
     dev = E.device
     topk = torch.empty(n, max_K, dtype=torch.int32, device=dev)
-    _lib.check(lib.lgcn_eval_topk(_lib.tp(E), Recmodel.n_users, Recmodel.m_items, Recmodel.latent_dim,
-                                  _lib.tp(ev.users32), n, _lib.tp(ev.train_ptr), _lib.tp(ev.train_idx32),
-                                  max_K, _lib.tp(topk), None, _lib.current_stream()), "lgcn_eval_topk")
+    _lib.check(lib.lgcn_eval_topk_masked(_lib.tp(E), Recmodel.n_users, Recmodel.m_items, Recmodel.latent_dim,
+                                         _lib.tp(ev.users32), n, _lib.tp(ev.train_ptr), _lib.tp(ev.train_idx32),
+                                         max_K, _lib.tp(topk), None, _lib.tp(ev.masks) if ev.masks is not None else None,
+                                         _lib.current_stream()), "lgcn_eval_topk")
     ks = torch.tensor(list(world.topks), dtype=torch.int32)
     per_user = torch.empty(n, 3 * len(ks), dtype=torch.float64, device=dev)
     sums = torch.empty(3 * len(ks), dtype=torch.float64, device=dev)
@@ -224,7 +236,7 @@ def Test(dataset, Recmodel, epoch, w=None, multicore=0):
             dataset._lgcn_eval_index = ev
         except Exception:
             pass
-    fused = max_K <= 32 and int(world.config.get('eval_fused', 1)) and hasattr(Recmodel, 'propagated_table')
+    fused = max_K <= 64 and int(world.config.get('eval_fused', 1)) and hasattr(Recmodel, 'propagated_table')
     if fused:
         with torch.no_grad():
             results, _ = _test_fused(Recmodel, ev, max_K)

@@ -76,6 +76,9 @@ SIGNATURES = {
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
     "lgcn_eval_topk": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "lgcn_eval_topk_masked": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "lgcn_eval_mask_words": (C.c_int64, [C.c_int32, C.c_int32]),
+    "lgcn_eval_build_masks": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_eval_topk_fp32": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_eval_metrics": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_dp_available": (C.c_int, []),

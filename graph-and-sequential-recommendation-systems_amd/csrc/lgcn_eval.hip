@@ -32,7 +32,7 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define EVAL_KMAX 32
+#define EVAL_KMAX 64
 #define EVAL_NEG_INF (-3.0e38f)
 #ifndef EVAL_PARTS
 #define EVAL_PARTS 3          /* workgroups per user block (<= 4) = workgroups that fit a CU with the compact lists */
@@ -66,6 +66,11 @@ struct EvalArgs {
     // K items at or above a part's K-th best exist, so every other part may use it as a floor for what it still inserts.
     // Any value ever published is valid, however stale -- the exchange only prunes, it never decides.
     float *thr_pub;
+    // Optional: the train-positive masks precomputed once per dataset (lgcn_eval_build_masks): masks[t * mask_stride + slot] =
+    // bit i set when item 32 t + i is a train positive of the user in evaluation slot `slot`.  With them the item sweep holds no
+    // global load besides the tile stream and one coalesced 128-byte mask load per wave and tile, issued a tile ahead (the
+    // cursor over the sorted train CSR costs a dependent load and a wait inside the loop).  NULL: the cursor.
+    const uint32_t *masks; int64_t mask_stride;
 };
 
 // c ? hi : lo.  The empty asm keeps the compiler from folding a tree of these over vector elements into ONE dynamically
@@ -103,7 +108,7 @@ static __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int D, int KS, typename IDT, int WGS, int NBUF = 2, bool SPLIT3 = false>
+template <int D, int KS, typename IDT, int WGS, int NBUF = 2, bool SPLIT3 = false, bool MASKS = false>
                                                                 // KS: list slots per lane (a multiple of 4, >= K); WGS: workgroups per CU;
                                                                 // NBUF: item tile buffers in LDS (1: one more barrier per tile)
 __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
@@ -153,7 +158,10 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
     int32_t nid = 0x7fffffff, nnid = 0x7fffffff;
     const int ntiles_all = (a.m_items + 31) / 32;
     const int t_begin = (int)((int64_t)ntiles_all * blockIdx.y / gridDim.y), t_end = (int)((int64_t)ntiles_all * (blockIdx.y + 1) / gridDim.y);
-    if (have && h == 0) {
+    uint32_t mask_next = 0;        // MASKS: this user's word of the NEXT tile, in flight under this tile's work
+    const uint32_t slot32 = (uint32_t)slot;     // (uniform row base + one 32-bit lane offset: slots past n_eval read their padding column, zeros)
+    if (MASKS) { if (t_begin < t_end) mask_next = (a.masks + (int64_t)t_begin * a.mask_stride)[slot32]; }
+    else if (have && h == 0) {
         tp = a.train_ptr[uid]; tend = a.train_ptr[uid + 1];
         if (t_begin > 0) {                                      // first train positive inside this workgroup's item range
             int64_t lo = tp, hi = tend;
@@ -211,12 +219,17 @@ __global__ void __launch_bounds__(256, WGS) k_eval_topk(EvalArgs a) {
         // ---- mask of this tile's train positives for my user
         const int base = t * 32;
         uint32_t mask = 0;
-        while (nid < base + 32) {                               // nid >= base always: tiles ascend
-            mask |= 1u << (nid - base);
-            nid = nnid; tp++;
-            nnid = (tp + 1 < tend) ? a.train_idx[tp + 1] : 0x7fffffff;
+        if (MASKS) {
+            mask = mask_next;                                   // both lanes of the user load the same word
+            if (t + 1 < t_end) mask_next = (a.masks + (int64_t)(t + 1) * a.mask_stride)[slot32];
+        } else {
+            while (nid < base + 32) {                           // nid >= base always: tiles ascend
+                mask |= 1u << (nid - base);
+                nid = nnid; tp++;
+                nnid = (tp + 1 < tend) ? a.train_idx[tp + 1] : 0x7fffffff;
+            }
+            mask = __shfl(mask, j);                             // lane j (h = 0) holds the user's mask
         }
-        mask = __shfl(mask, j);                                 // lane j (h = 0) holds the user's mask
         // ---- 32 items x 32 users: scores[item i][user j] = sum_k I[i][k] U[j][k]
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT3) {
@@ -420,27 +433,62 @@ __global__ void __launch_bounds__(256) k_eval_sum(const double *per_user, int32_
     }
 }
 
+// masks[t * stride + slot]: one wave per evaluation slot walks the user's train positives
+__global__ void __launch_bounds__(256) k_eval_masks(const int32_t *users, int32_t n_eval, const int64_t *train_ptr, const int32_t *train_idx,
+                                                    int32_t m_items, uint32_t *masks, int64_t stride) {
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= n_eval) return;
+    const int32_t u = users[slot];
+    const int64_t b = train_ptr[u], e = train_ptr[u + 1];
+    for (int64_t i = b + (threadIdx.x & 63); i < e; i += 64) {
+        const int32_t it = train_idx[i];
+        if (it >= 0 && it < m_items) atomicOr(masks + (int64_t)(it >> 5) * stride + slot, 1u << (it & 31));
+    }
+}
+
+static inline int64_t eval_mask_stride(int32_t n_eval) { return ((int64_t)n_eval + 127) / 128 * 128; }
+
+extern "C" int64_t lgcn_eval_mask_words(int32_t m_items, int32_t n_eval) {
+    if (m_items <= 0 || n_eval <= 0) return 0;
+    return (int64_t)((m_items + 31) / 32) * eval_mask_stride(n_eval);
+}
+
+extern "C" int lgcn_eval_build_masks(const int32_t *users, int32_t n_eval, const int64_t *train_indptr, const int32_t *train_indices,
+                                     int32_t m_items, uint32_t *masks, void *stream) {
+    if (!users || !train_indptr || !train_indices || !masks || m_items <= 0 || n_eval < 0) { lgcn_set_error("lgcn_eval_build_masks: invalid argument"); return 3; }
+    if (n_eval == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t stride = eval_mask_stride(n_eval);
+    if (hipMemsetAsync(masks, 0, sizeof(uint32_t) * (size_t)lgcn_eval_mask_words(m_items, n_eval), st) != hipSuccess) { lgcn_set_error("lgcn_eval_build_masks: memset failed"); return 10; }
+    hipLaunchKernelGGL(k_eval_masks, dim3((unsigned)((n_eval + 3) / 4)), dim3(256), 0, st, users, n_eval, train_indptr, train_indices, m_items, masks, stride);
+    if (hipGetLastError() != hipSuccess) { lgcn_set_error("lgcn_eval_build_masks: launch failed"); return 10; }
+    return 0;
+}
+
 static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
                      const int32_t *users, int32_t n_eval,
                      const int64_t *train_indptr, const int32_t *train_indices,
-                     int32_t K, int32_t *topk_items, float *topk_scores, void *stream, bool split3) {
+                     int32_t K, int32_t *topk_items, float *topk_scores, const uint32_t *masks, void *stream, bool split3) {
     if (!E || !users || !train_indptr || !train_indices || !topk_items || n_users <= 0 || m_items <= 0 || n_eval < 0) {
         lgcn_set_error("lgcn_eval_topk: invalid argument"); return 3;
     }
-    if (K < 1 || K > EVAL_KMAX || K > m_items) { lgcn_set_error("lgcn_eval_topk: K must be in 1..32 and <= m_items"); return 3; }
+    if (K < 1 || K > EVAL_KMAX || K > m_items) { lgcn_set_error("lgcn_eval_topk: K must be in 1..64 and <= m_items"); return 3; }
     if (n_eval == 0) return 0;
-    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr, nullptr};
+    EvalArgs a{E, n_users, m_items, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, nullptr, nullptr,
+               masks, eval_mask_stride(n_eval)};
     const unsigned blocks = (unsigned)((n_eval + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     // The item sweep is split over `parts` workgroups per user block, as many as fit a CU together, so that one's list
     // maintenance runs under the others' MFMAs.  Compact lists (16-bit ids relative to the part's first item: d <= 64,
-    // K <= 20, at most 2047 tiles per part) make that three; otherwise two (d <= 64, K <= 20) or one.
+    // at most 2047 tiles per part) make that three for K <= 20 and two for K <= 64 (the lists grow with K); d = 128: two
+    // for K <= 20; otherwise one workgroup per CU with int32 ids and the fp32 matrix instructions.
     // (measured on Gowalla with int32 ids, two per CU: 1 / 2 / 3 / 4 parts = 3.40 / 2.54 / 2.79 / 2.70 ms)
     const int ntiles = (m_items + 31) / 32;
-    const bool split = d <= 128 && K <= 20 && m_items >= 4096;
-    const int want = d <= 64 ? EVAL_PARTS : 2;                 // d = 128: 256 registers, two workgroups per CU
+    const bool small = K <= 20;
+    const bool split = m_items >= 4096 && ((d <= 128 && small) || d <= 64);
+    const int want = (d <= 64 && small) ? EVAL_PARTS : 2;      // d = 128: 256 registers; K > 20: 64-slot lists -- two workgroups per CU
     const bool id16 = split && (ntiles + want - 1) / want + 1 <= EVAL_ID16_MAX_TILES;
-    const int parts = id16 ? want : split ? 2 : 1;
+    const int parts = id16 ? want : (split && small) ? 2 : 1;
     void *tmp = nullptr;
     bool tmp_sync = false;
     if (parts > 1) {
@@ -460,24 +508,31 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
         }
     }
     const dim3 grid(blocks, parts);
-#define EVAL_LAUNCH(DD) do { if (K <= 20) hipLaunchKernelGGL((k_eval_topk<DD, 20, int32_t, 1>), grid, dim3(256), 0, st, a); \
-                            else hipLaunchKernelGGL((k_eval_topk<DD, 32, int32_t, 1>), grid, dim3(256), 0, st, a); } while (0)
-#define EVAL_LAUNCH_SMALL(DD) do { if (id16 && split3) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, true>), grid, dim3(256), 0, st, a); \
-                                  else if (id16) hipLaunchKernelGGL((k_eval_topk<DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, false>), grid, dim3(256), 0, st, a); \
-                                  else EVAL_LAUNCH(DD); } while (0)
+    const bool mk = masks != nullptr;
+#define EV(...) do { if (mk) hipLaunchKernelGGL((k_eval_topk<__VA_ARGS__, true>), grid, dim3(256), 0, st, a); \
+                     else hipLaunchKernelGGL((k_eval_topk<__VA_ARGS__, false>), grid, dim3(256), 0, st, a); } while (0)
+    // the generic form: int32 ids, one workgroup per CU, fp32 matrix instructions
+#define EVAL_GENERIC(DD) do { if (K <= 20) EV(DD, 20, int32_t, 1, 2, false); else if (K <= 32) EV(DD, 32, int32_t, 1, 2, false); \
+                              else EV(DD, 64, int32_t, 1, (DD >= 256 ? 1 : 2), false); } while (0)
+#define EVAL_SMALL(DD) do { if (id16 && small && split3) EV(DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, true); \
+                            else if (id16 && small) EV(DD, 20, uint16_t, EVAL_PARTS, EVAL_NBUF, false); \
+                            else if (id16 && split3) EV(DD, 64, uint16_t, 2, 2, true); \
+                            else if (id16) EV(DD, 64, uint16_t, 2, 2, false); \
+                            else EVAL_GENERIC(DD); } while (0)
     switch (d) {
-    case 32: EVAL_LAUNCH_SMALL(32); break;
-    case 64: EVAL_LAUNCH_SMALL(64); break;
+    case 32: EVAL_SMALL(32); break;
+    case 64: EVAL_SMALL(64); break;
     case 128:
-        if (id16 && split3) hipLaunchKernelGGL((k_eval_topk<128, 20, uint16_t, 2, 1, true>), grid, dim3(256), 0, st, a);
-        else if (id16) hipLaunchKernelGGL((k_eval_topk<128, 20, uint16_t, 2, 2, false>), grid, dim3(256), 0, st, a);
-        else EVAL_LAUNCH(128);
+        if (id16 && small && split3) EV(128, 20, uint16_t, 2, 1, true);
+        else if (id16 && small) EV(128, 20, uint16_t, 2, 2, false);
+        else EVAL_GENERIC(128);
         break;
-    case 256: EVAL_LAUNCH(256); break;
+    case 256: EVAL_GENERIC(256); break;
     default: if (tmp) { if (tmp_sync) (void)hipFree(tmp); else (void)hipFreeAsync(tmp, st); } lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3;
     }
-#undef EVAL_LAUNCH_SMALL
-#undef EVAL_LAUNCH
+#undef EVAL_SMALL
+#undef EVAL_GENERIC
+#undef EV
     if (parts > 1) {
         hipLaunchKernelGGL(k_eval_merge, dim3((unsigned)((n_eval + 255) / 256)), dim3(256), 0, st, a, parts);
         if (tmp_sync) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
@@ -490,13 +545,19 @@ static int eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d
 extern "C" int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d, const int32_t *users, int32_t n_eval,
                               const int64_t *train_indptr, const int32_t *train_indices, int32_t K, int32_t *topk_items,
                               float *topk_scores, void *stream) {
-    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, stream, EVAL_SPLIT3 != 0);
+    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, stream, EVAL_SPLIT3 != 0);
+}
+
+extern "C" int lgcn_eval_topk_masked(const float *E, int32_t n_users, int32_t m_items, int32_t d, const int32_t *users, int32_t n_eval,
+                                     const int64_t *train_indptr, const int32_t *train_indices, int32_t K, int32_t *topk_items,
+                                     float *topk_scores, const uint32_t *masks, void *stream) {
+    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, masks, stream, EVAL_SPLIT3 != 0);
 }
 
 extern "C" int lgcn_eval_topk_fp32(const float *E, int32_t n_users, int32_t m_items, int32_t d, const int32_t *users, int32_t n_eval,
                                    const int64_t *train_indptr, const int32_t *train_indices, int32_t K, int32_t *topk_items,
                                    float *topk_scores, void *stream) {
-    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, stream, false);
+    return eval_topk(E, n_users, m_items, d, users, n_eval, train_indptr, train_indices, K, topk_items, topk_scores, nullptr, stream, false);
 }
 
 extern "C" int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,

@@ -278,14 +278,27 @@ int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t 
  * set to -(1<<10) (Procedure.py:177-181; CSR with int64 indptr[n_users+1] and ascending int32
  * indices = dataset.allPos), top-K (Procedure.py:183) -- in one kernel, the [users, m_items]
  * score matrix is never materialised.  topk_items [n_eval,K] int32, best first (ties: lower
- * item id first); topk_scores [n_eval,K] or NULL.  1 <= K <= 32.                          */
+ * item id first; when the sweep is split over several workgroups per user block -- catalogues of >= 4096 items -- the
+ * order of two items whose scores tie EXACTLY at the K-th place is unspecified, as torch.topk's is);
+ * topk_scores [n_eval,K] or NULL.  1 <= K <= 64 (Procedure.py:183 takes k = max(topks)).          */
 int lgcn_eval_topk(const float *E, int32_t n_users, int32_t m_items, int32_t d,
                    const int32_t *users, int32_t n_eval,
                    const int64_t *train_indptr, const int32_t *train_indices,
                    int32_t K, int32_t *topk_items, float *topk_scores, void *stream);
+/* The same with the train-positive masks precomputed ONCE per dataset instead of walked from the CSR inside the sweep:
+ * masks = lgcn_eval_mask_words(m_items, n_eval) uint32 words filled by lgcn_eval_build_masks (word [t * stride + slot],
+ * stride = n_eval rounded up to 128: bit i = item 32 t + i is a train positive of users[slot]).  The sweep then holds
+ * no global load besides the item tiles and one coalesced mask load per wave and tile.  Same results.          */
+int64_t lgcn_eval_mask_words(int32_t m_items, int32_t n_eval);
+int lgcn_eval_build_masks(const int32_t *users, int32_t n_eval, const int64_t *train_indptr, const int32_t *train_indices,
+                          int32_t m_items, uint32_t *masks, void *stream);
+int lgcn_eval_topk_masked(const float *E, int32_t n_users, int32_t m_items, int32_t d,
+                          const int32_t *users, int32_t n_eval,
+                          const int64_t *train_indptr, const int32_t *train_indices,
+                          int32_t K, int32_t *topk_items, float *topk_scores, const uint32_t *masks, void *stream);
 /* The same, with every score produced by the fp32 matrix instructions (v_mfma_f32_32x32x2_f32).  lgcn_eval_topk itself
- * computes the fp32 product on the bf16 matrix cores where it can (d <= 64, K <= 20, at most 196 K items per third of
- * the catalogue): both operands split EXACTLY into three bf16 values each, six of the nine product planes accumulated in
+ * computes the fp32 product on the bf16 matrix cores where it can (d <= 64, at most 65 K items per part of the catalogue: three parts for
+ * K <= 20, two for K <= 64; d = 128 with K <= 20): both operands split EXACTLY into three bf16 values each, six of the nine product planes accumulated in
  * fp32 -- the planes left out are below the rounding of an fp32 dot product, so both entry points are fp32-accurate and
  * may differ only where two scores tie within that rounding.  This one is the slower cross-check.          */
 int lgcn_eval_topk_fp32(const float *E, int32_t n_users, int32_t m_items, int32_t d,

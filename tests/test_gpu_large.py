@@ -205,7 +205,8 @@ def test_c5_full_shape(pkg, oracle):
     # Right: M y = lgcn_propagate_mean on y in fp32 -- the forward this test has just checked layer by layer against the oracle --
     # and G = oracle.bpr (model.py:162-183 + its analytic gradient) on the propagated batch rows.  Tolerance: the two sides are
     # sums of ~1e9 fp32 products whose terms carry the rounding of 2K - 1 launches (rows of up to 800 000 terms); it is stated
-    # against the sum of ABSOLUTE values  Aabs = <M |y|, |G|>  (computed with the same operator): 64 * 2^-24 * Aabs in fp32;
+    # against the sum of ABSOLUTE values  Aabs = <M |y|, |G|>  (computed with the same operator): 4 * 2^-24 * Aabs in fp32
+    # (measured: 1e-11 * Aabs -- the rounding errors of 1e9 terms average out; one dropped 2 048-entry chunk of one hub row is ~1e-5);
     # with bf16 activation storage the K - 1 stored backward intermediates are each rounded to 8 significant bits
     # (2^-9 relative), so + (K - 1) * 2^-9 * Aabs there.  A dropped or doubled term (a layer, the hub rows, a slot block)
     # changes the left side by O(Aabs / (K + 1)).
@@ -244,8 +245,8 @@ def test_c5_full_shape(pkg, oracle):
         for what, mask in cases:
             if mask == "off_batch":
                 y[batch_rows_t] = 0.0
-            elif mask == "hubs":
-                keep = y[hubs_t].clone(); y.zero_(); y[hubs_t] = keep
+            elif mask == "hubs":                 # (fresh values: the top hub is a batch row, zeroed by the case before)
+                y.zero_(); y[hubs_t] = torch.randn(len(hubs), d, device=DEV, generator=gen)
             lhs = dot64(y, gm) / float(w1)
             My = mean_propagate(y)
             rhs = float((My[batch_rows_t].double() * G_t).sum())
@@ -254,7 +255,7 @@ def test_c5_full_shape(pkg, oracle):
             Mya = mean_propagate(ya)
             aabs = float((Mya[batch_rows_t].double() * G_t.abs()).sum())
             del Mya, ya
-            tol = 64 * EPS32 * aabs + (0.0 if act == "fp32" else (K - 1) * 2.0 ** -9 * aabs)
+            tol = 4 * EPS32 * aabs + (0.0 if act == "fp32" else (K - 1) * 2.0 ** -9 * aabs)
             print(f"[c5 adjoint {act}: {what}] <y,g> {lhs:.9e}  <My,G> {rhs:.9e}  diff {abs(lhs - rhs):.3e}  "
                   f"Aabs {aabs:.3e}  diff/Aabs {abs(lhs - rhs) / aabs:.3e}  tol/Aabs {tol / aabs:.3e}")
             assert aabs > 0 and abs(lhs - rhs) <= tol, (act, what, lhs, rhs, aabs, tol)

@@ -1159,11 +1159,15 @@ def test_dp_empty_trailing_shard(pkg, tiny, tmp_path):
 
 
 @pytest.mark.parametrize("m_items,d,K,n_eval", [(5000, 64, 20, 300), (4100, 32, 7, 130), (200000, 64, 20, 160), (9000, 64, 25, 129),
-                                                (6000, 128, 20, 200)])
+                                                (6000, 128, 20, 200), (9000, 64, 50, 200), (7000, 32, 64, 129), (3000, 64, 50, 140),
+                                                (6000, 128, 50, 130), (150000, 64, 50, 130)])
 def test_eval_topk_every_sweep_form_vs_torch(pkg, m_items, d, K, n_eval):
     """lgcn_eval_topk on synthetic tables, one case per form of the item sweep: three workgroups per user block with compact
     lists (16-bit ids relative to the part's first item; d <= 64, K <= 20), two with int32 ids (parts too long for 16 bits),
-    one (K > 20 or d > 64).  Train positives clustered inside single 32-item tiles, at the part boundaries and at the table's
+    one (d > 64 with K > 20, or a catalogue under 4096 items); K = 25 / 50 / 64 (Procedure.py:183 takes k = max(topks): --topks "[20,50]")
+    on two workgroups per block with 64-slot lists, and on the generic form at d = 128 and on 150 000 items.  Every case also
+    through lgcn_eval_topk_masked (train-positive masks precomputed by lgcn_eval_build_masks instead of the in-sweep cursor):
+    bit-identical lists.  Train positives clustered inside single 32-item tiles, at the part boundaries and at the table's
     end; an unsorted, repeating user list.  Against torch matmul + mask + topk: same ids in the same order except where two
     scores tie within fp32 rounding, masked items never returned."""
     L, lib = pkg._lib, pkg._lib.load()
@@ -1221,6 +1225,25 @@ def test_eval_topk_every_sweep_form_vs_torch(pkg, m_items, d, K, n_eval):
     assert float((topk32 == topk).float().mean()) > 0.999
     assert float((sc32.double() - sc.double()).abs().max()) < tol
     assert float((torch.gather(exact, 1, topk32.long()) - want_sc).abs().max()) < tol
+    # precomputed train-positive masks instead of the cursor: the same kernel arithmetic, so the same bits
+    words = int(lib.lgcn_eval_mask_words(m_items, n_eval))
+    assert words == ((m_items + 31) // 32) * ((n_eval + 127) // 128 * 128)
+    masks = torch.full((words,), -1, dtype=torch.int32, device=DEV)          # (build must zero it)
+    L.check(lib.lgcn_eval_build_masks(L.tp(d_users), n_eval, L.tp(d_ptr), L.tp(d_idx), m_items, L.tp(masks), L.current_stream()), "masks")
+    stride = (n_eval + 127) // 128 * 128
+    mk = masks.view(ntiles, stride).cpu().numpy().view(np.uint32)
+    for s_ in (0, n_eval // 2, n_eval - 1):
+        want_bits = np.zeros(ntiles, np.uint32)
+        for it in rows[users[s_]]:
+            want_bits[it >> 5] |= np.uint32(1) << np.uint32(it & 31)
+        assert np.array_equal(mk[:, s_], want_bits)
+    assert not mk[:, n_eval:].any()
+    topk_m = torch.full((n_eval, K), -7, dtype=torch.int32, device=DEV)
+    sc_m = torch.empty(n_eval, K, dtype=torch.float32, device=DEV)
+    L.check(lib.lgcn_eval_topk_masked(L.tp(E), n_users, m_items, d, L.tp(d_users), n_eval, L.tp(d_ptr), L.tp(d_idx), K,
+                                      L.tp(topk_m), L.tp(sc_m), L.tp(masks), L.current_stream()), "lgcn_eval_topk_masked")
+    assert torch.equal(sc_m, sc)
+    assert float((topk_m == topk).float().mean()) > 0.9999          # (the parts' threshold exchange is timing dependent: an exact tie at the K-th place may pick the other id)
 
 
 @pytest.mark.parametrize("which", ["lastfm", "tiny"])
@@ -1265,7 +1288,7 @@ def test_fused_eval_kernels_vs_torch_and_oracle(pkg, oracle, tiny, lastfm, tmp_p
     # argument checks
     L = pkg._lib
     assert L.load().lgcn_eval_topk(L.tp(E), ds.n_users, ds.m_items, g.d, L.tp(ev.users32), len(ev.users), L.tp(ev.train_ptr),
-                                   L.tp(ev.train_idx32), 33, L.tp(topk), None, L.current_stream()) == 3
+                                   L.tp(ev.train_idx32), 65, L.tp(topk), None, L.current_stream()) == 3      # K <= 64
 
 
 @pytest.mark.parametrize("which,world", [("tiny", 2), ("tiny", 3), ("lastfm", 4)])
