@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="gowalla", choices=list(WORKLOADS))
-    ap.add_argument("--act_dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--act_dtype", default="fp32", choices=["fp32", "bf16", "fp8"])
     ap.add_argument("--xcd_remap", type=int, default=1)
     ap.add_argument("--dense_last", default="auto", choices=["auto", "0", "1"], help="last forward layer: on the batch rows only (0) or densely (1)")
     ap.add_argument("--row_order", default=None, choices=["natural", "rcm", "cocluster", "xcd"])
@@ -138,8 +138,9 @@ def main():
     ap.add_argument("--spmm_reps", type=int, default=2000, help="launches of the dominant kernel timed live for the roofline object (2000 x ~27 us: a 50 ms average)")
     ap.add_argument("--dp_reduce", default="rows", choices=["rows", "dense"],
                     help="data-parallel gradient exchange: all-gather of gradient rows (default) or dense all-reduce")
-    ap.add_argument("--dp_shard", default="batch", choices=["batch", "rows"],
-                    help="batch: replicated propagation, sharded batch; rows: row-sharded propagation too")
+    ap.add_argument("--dp_shard", default="batch", choices=["batch", "rows", "cols"],
+                    help="batch: replicated propagation, sharded batch; rows: row-sharded propagation too; cols: every rank holds "
+                         "d / N columns of the tables and sees the whole batch (one all-reduce of 3*B floats per step; d / N must be 32..256)")
     ap.add_argument("--force_dp", action="store_true", help="use the data-parallel step (RCCL) even at world size 1")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong (default) = the reference's step, ONE global batch of B triplets sharded over the ranks "
@@ -152,6 +153,7 @@ def main():
     ap.add_argument("--data_dir", default=os.path.join(tempfile.gettempdir(), "lgcn_bench_data"))
     a = ap.parse_args()
     n_users, m_items, E, K, d, B, dsteps, dwarm = WORKLOADS[a.workload]
+    d_full = d
     if a.steps is None:
         a.steps = dsteps
     if a.warmup is None:
@@ -224,20 +226,28 @@ def main():
         progress("adjacency built")
         pkg.sampling.seed(2020)
         pkg.utils.set_seed(2020)
-        model = pkg.model.LightGCN(w.config, ds).to(dev)
+        if use_dp and a.dp_shard == "cols":
+            model = pkg.parallel.column_shard(pkg.model.LightGCN, w.config, ds, world, rank, dev)
+            d_full, d = d, model.latent_dim        # this rank's width: what its kernels run at
+        else:
+            model = pkg.model.LightGCN(w.config, ds).to(dev)
     progress("model on the device")
     N = ds.n_users + ds.m_items
     nnz = int(ds.getSparseGraphCSR().nnz)
-    s = 4 if a.act_dtype == "fp32" else 2
-    adt = 0 if a.act_dtype == "fp32" else 1
+    ACT = {"fp32": (0, 4.0), "bf16": (1, 2.0), "fp8": (2, 1.0 + 4.0 / d)}     # code, bytes per stored element (fp8: + the row scale)
+    adt, s = ACT[a.act_dtype]
+    ADT_NAME = {0: "fp32", 1: "bf16", 2: "fp8"}
     L = pkg._lib
     lib_hash = pkg.build.kernel_hash()
 
     def spmm_kernel_time(reps, adt=adt):
         """dominant kernel (dense CSR-SpMM layer) timed live with HIP events on the launch stream"""
         st = model._state()
-        tdt = torch.float32 if adt == 0 else torch.bfloat16
-        x = (torch.randn(N, d, device=dev) * 0.1).to(tdt)     # same graph object (same row order) as the step
+        x = torch.randn(N, d, device=dev) * 0.1               # same graph object (same row order) as the step
+        if adt == 2:
+            x = st['graph'].to_fp8(x)
+        elif adt == 1:
+            x = x.to(torch.bfloat16)
         y = torch.empty_like(x)
         lib = L.load()
         stream = L.current_stream()
@@ -255,11 +265,11 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e-3
 
     def roofline(t_spmm, adt=adt):
-        s = 4 if adt == 0 else 2
+        s = ACT[ADT_NAME[adt]][1]
         bytes_spmm = spmm_bytes(N, nnz, d, s)
         achieved = bytes_spmm / t_spmm / 1e9
-        traffic, note = read_traffic(f"{a.workload}:{'fp32' if adt == 0 else 'bf16'}:k_spmm", lib_hash)
-        return {"bound": "hbm", "kernel": f"k_spmm<{d},{'float' if adt == 0 else 'bf16'}> (dense CSR-SpMM layer)",
+        traffic, note = read_traffic(f"{a.workload}:{ADT_NAME[adt]}:k_spmm", lib_hash)
+        return {"bound": "hbm", "kernel": f"k_spmm<{d},{ {0: 'float', 1: 'bf16', 2: 'fp8'}[adt] }> (dense CSR-SpMM layer)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": note, "algorithmic_bytes_per_launch": bytes_spmm,
                 "avg_launch_us": t_spmm * 1e6, "gather_bytes_upper_bound": nnz * d * s,
@@ -315,7 +325,7 @@ def main():
     reps = a.spmm_reps if a.workload != "synthetic-10m" else 5
     secondary = None
     if rank == 0 and not use_dp and not a.no_secondary and a.workload != "synthetic-10m":
-        other = "bf16" if a.act_dtype == "fp32" else "fp32"
+        other = "bf16" if a.act_dtype != "bf16" else "fp32"
         cfg2 = dict(w.config); cfg2['act_dtype'] = other
         with contextlib.redirect_stdout(io.StringIO()):
             pkg.utils.set_seed(2020)
@@ -325,7 +335,7 @@ def main():
         model2.fused_epoch(users[a.warmup * B:(a.warmup + a.steps) * B], pos[a.warmup * B:(a.warmup + a.steps) * B],
                            neg[a.warmup * B:(a.warmup + a.steps) * B], B)
         torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
-        secondary = (other, a.steps / dt2, spmm_kernel_time(max(200, reps // 4), 1 - adt))
+        secondary = (other, a.steps / dt2, spmm_kernel_time(max(200, reps // 4), ACT[other][0]))
         del model2
     t_spmm = spmm_kernel_time(reps)      # ~3 ms of back-to-back launches, directly ahead of the warm-up steps
 
@@ -374,6 +384,8 @@ def main():
                    + ("gradient-row all-gather" if a.dp_reduce == "rows" else "dense gradient all-reduce")
                    + (" + row-sharded propagation with one all-gather per layer" if a.dp_shard == "rows" else "")
                    + " over RCCL)")
+            if a.dp_shard == "cols":
+                par = f"dp{world} (column-sharded tables: {d} of {d * world} columns per rank, whole batch on every rank, one all-reduce of 3*B floats per step over RCCL)"
         out = {
             # `value` = GLOBAL optimizer steps per second in both modes (never multiplied by the world size: with replicated
             # propagation every rank repeats the 2K-1 SpMMs, so this number is ~flat in N by construction of the algorithm;
@@ -381,10 +393,10 @@ def main():
             "metric": f"BPR training steps/sec (one step = K-layer LightGCN propagation + BPR loss + backward + Adam on a global batch of {Bg} triplets)",
             "value": steps_per_sec, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1000.0 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "f32" if a.act_dtype == "fp32" else "f32 accumulate, bf16 activation storage",
+            "dtype": "f32" if a.act_dtype == "fp32" else f"f32 accumulate, {a.act_dtype} activation storage",
             "data": data_kind,
             "config": {"workload": f"{a.workload}: {ds.n_users} users x {ds.m_items} items, {ds.trainDataSize} train "
-                                   f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d}, bpr_batch={B}",
+                                   f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d_full}, bpr_batch={B}",
                        "global_batch": Bg, "per_gpu_batch": (Bg + world - 1) // world, "global_steps_per_sec": steps_per_sec,
                        "triplets_per_sec": steps_per_sec * Bg, "batches_of_B_per_sec": steps_per_sec * Bg / B,
                        "scaling_mode": a.scaling, "multi_gpu_status": "unmeasured on multi-GPU hardware by the builder (1-GPU boxes only)" if world > 1 else "n/a",
@@ -402,7 +414,7 @@ def main():
         if secondary is not None:       # the same workload with the other activation storage type (reported, not the headline)
             out["config"][f"{secondary[0]}_activation_storage_steps_per_sec"] = secondary[1]
             # the dominant kernel of that other mode (BASELINE configs[1] names bf16 activation storage), same definition
-            out[f"roofline_{secondary[0]}"] = roofline(secondary[2], 1 - adt)
+            out[f"roofline_{secondary[0]}"] = roofline(secondary[2], ACT[secondary[0]][0])
         out["roofline"] = roofline(t_spmm)
 
     # ---- the evaluation kernel on the same model (reported, not the headline): Procedure.Test's scoring +

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ABI_VERSION = 10
 MAX_LAYERS = 8
 
@@ -43,6 +43,8 @@ SIGNATURES = {
     "lgcn_abi_version": (C.c_int, []),
     "lgcn_last_error": (C.c_char_p, []),
     "lgcn_device_available": (C.c_int, []),
+    "lgcn_table_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "lgcn_to_fp8": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp]),
     "lgcn_sampling_seed": (None, [C.c_uint]),
     "lgcn_sampling_randint": (C.c_int, [C.c_int]),
     "lgcn_sample_negative": (C.c_int, [C.c_int, C.c_int, C.c_int64, _vp, _vp, C.c_int, _vp]),
@@ -84,6 +86,8 @@ SIGNATURES = {
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),
     "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lgcn_train_step_cols_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp), _vp]),
+    "lgcn_train_step_cols_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_dp_allreduce_sum_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "lgcn_dp_init_loopback": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lgcn_dp_destroy": (None, [_vp]),
@@ -203,6 +207,33 @@ class Graph:
                                        npp(xs) if xs is not None else None, C.byref(h)), "lgcn_graph_create")
         self.handle = h
 
+    def to_fp8(self, x):
+        """fp32 [n_rows, d] -> the library's fp8 table (uint8 tensor: n_rows*d E4M3 bytes, then n_rows fp32 row scales, padded)."""
+        import torch
+        x = x.contiguous().float()
+        n, d = int(x.shape[0]), int(x.shape[1])
+        out = torch.zeros(int(load().lgcn_table_bytes(n, d, FP8)), dtype=torch.uint8, device=x.device)
+        check(load().lgcn_to_fp8(tp(x), tp(out), n, d, current_stream()), "lgcn_to_fp8")
+        return out
+
+    @staticmethod
+    def from_fp8(tab, n, d):
+        """decode an fp8 table (as to_fp8 / an fp8 SpMM output lays it out) to fp32 [n, d] with torch (test helper)"""
+        import torch
+        q = tab[:n * d].view(torch.float8_e4m3fn).view(n, d).float()
+        sc = tab[n * d:n * d + 4 * n].view(torch.float32)
+        return q * sc[:, None]
+
+    def spmm_fp8(self, xq, d, y_dtype=FP8):
+        """A @ X for an fp8 table xq (see to_fp8): -> fp8 table (y_dtype FP8) or fp32 [n_rows, d] (F32)."""
+        import torch
+        if y_dtype == FP8:
+            y = torch.zeros(int(load().lgcn_table_bytes(self.n_rows, d, FP8)), dtype=torch.uint8, device=xq.device)
+        else:
+            y = torch.empty(self.n_rows, d, dtype=torch.float32, device=xq.device)
+        check(load().lgcn_spmm_csr(self.handle, tp(xq), FP8, tp(y), y_dtype, int(d), current_stream()), "lgcn_spmm_csr")
+        return y
+
     def spmm(self, x, y_dtype=None):
         import torch
         if x.dim() != 2 or x.shape[0] != self.n_rows or x.shape[1] not in (32, 64, 128, 256) or x.shape[1] > self.d_max:
@@ -215,7 +246,10 @@ class Graph:
         if xd == F32:
             x = x.float()
         yd = xd if y_dtype is None else y_dtype
-        y = torch.empty(x.shape, dtype=torch.bfloat16 if yd == BF16 else torch.float32, device=x.device)
+        if yd == FP8:
+            y = torch.zeros(int(load().lgcn_table_bytes(self.n_rows, int(x.shape[1]), FP8)), dtype=torch.uint8, device=x.device)
+        else:
+            y = torch.empty(x.shape, dtype=torch.bfloat16 if yd == BF16 else torch.float32, device=x.device)
         check(load().lgcn_spmm_csr(self.handle, tp(x), xd, tp(y), yd, int(x.shape[1]), current_stream()), "lgcn_spmm_csr")
         return y
 

@@ -50,6 +50,16 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(16))) __bf16 bf16x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// LGCN_FP8: a table of n rows is  n * D bytes of OCP E4M3 values  followed by  n fp32 ROW SCALES  (value = scale * fp8): one
+// pointer names both.  Scales are powers of two with max|row| / scale in [64, 128) (inside the range of both E4M3 flavours;
+// a division by a power of two is exact, so the quantisation is a pure fp8 rounding the tests restate bit for bit).
+struct fp8_t { uint8_t v; };
+__device__ __forceinline__ const float *fp8_scales(const void *tab, int64_t n_rows, int D) { return (const float *)((const char *)tab + n_rows * D); }
+__device__ __forceinline__ float *fp8_scales(void *tab, int64_t n_rows, int D) { return (float *)((char *)tab + n_rows * D); }
 
 #ifndef LGCN_GATHER_U
 #define LGCN_GATHER_U 8      /* max row gathers in flight per lane (8 x 16 B raw = 32 VGPRs) */
@@ -61,6 +71,7 @@ typedef __bf16 bf16_t;
 template <int C> struct VecF;
 template <> struct VecF<4> { typedef f32x4 T; typedef bf16x4 B; };
 template <> struct VecF<8> { typedef f32x8 T; typedef bf16x8 B; };
+template <> struct VecF<16> { typedef f32x16 T; typedef bf16x16 B; };
 
 template <int C> __device__ __forceinline__ typename VecF<C>::T zerov() {
     typename VecF<C>::T z;
@@ -84,6 +95,53 @@ __device__ __forceinline__ f32x4 load4(const float *p) { return loadv<4>(p); }
 __device__ __forceinline__ f32x4 load4(const bf16_t *p) { return loadv<4>(p); }
 __device__ __forceinline__ void store4(float *p, f32x4 v) { storev<4>(p, v); }
 __device__ __forceinline__ void store4(bf16_t *p, f32x4 v) { storev<4>(p, v); }
+// one fp8 element of a table, decoded (k_triplet's lower-layer rows: lane = column)
+__device__ __forceinline__ float fp8_decode(uint8_t b) { return __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false)[0]; }
+template <typename TI> __device__ __forceinline__ float tab_elem(const void *tab, int64_t n_rows, int D, int64_t row, int col);
+template <> __device__ __forceinline__ float tab_elem<float>(const void *tab, int64_t, int D, int64_t row, int col) { return ((const float *)tab)[row * D + col]; }
+template <> __device__ __forceinline__ float tab_elem<bf16_t>(const void *tab, int64_t, int D, int64_t row, int col) { return (float)((const bf16_t *)tab)[row * D + col]; }
+template <> __device__ __forceinline__ float tab_elem<fp8_t>(const void *tab, int64_t n_rows, int D, int64_t row, int col) {
+    return fp8_scales(tab, n_rows, D)[row] * fp8_decode(((const uint8_t *)tab)[row * D + col]);
+}
+// scale of a row whose largest magnitude is amax: 2^(e - 6) for amax = 1.f * 2^e  ->  amax / scale in [64, 128); rows
+// below 2^-100 (and zero rows) are stored as zeros with scale 1; every other finite row, up to the top of fp32, is scaled
+__device__ __forceinline__ void fp8_row_scale(float amax, float &scale, float &inv) {
+    const uint32_t E = __float_as_uint(amax) >> 23;           // biased exponent (amax >= 0)
+    if (E < 27u || E == 255u) { scale = 1.f; inv = E == 255u ? 1.f : 0.f; return; }      // (inf / NaN rows stay inf / NaN)
+    scale = __uint_as_float((E - 6u) << 23); inv = __uint_as_float((260u - E) << 23);
+}
+// Store one row piece of C values per lane as fp8: the row's LPR = D / C lanes (contiguous, aligned, all active) agree on
+// the row maximum through xor shuffles, every lane quantises its piece, lane l == 0 writes the scale.
+template <int D, int C>
+__device__ __forceinline__ void store_row_fp8(void *tab, int64_t n_rows, int64_t row, int l, typename VecF<C>::T v) {
+    constexpr int LPR = D / C;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; i++) amax = fmaxf(amax, fabsf(v[i]));
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    float scale, inv;
+    fp8_row_scale(amax, scale, inv);
+    uint32_t w[C / 4];
+#pragma unroll
+    for (int i = 0; i < C / 4; i++) {
+        int p = 0;
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i] * inv, v[4 * i + 1] * inv, p, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, p, true);
+        w[i] = (uint32_t)p;
+    }
+    uint32_t *dst = (uint32_t *)((char *)tab + row * D + l * C);
+#pragma unroll
+    for (int i = 0; i < C / 4; i++) dst[i] = w[i];
+    if (l == 0) fp8_scales(tab, n_rows, D)[row] = scale;
+}
+// row piece store by output type
+template <int D, int C, typename TO> struct RowStore {
+    static __device__ __forceinline__ void put(void *Y, int64_t, int64_t row, int l, typename VecF<C>::T v) { storev<C>((TO *)Y + row * D + l * C, v); }
+};
+template <int D, int C> struct RowStore<D, C, fp8_t> {
+    static __device__ __forceinline__ void put(void *Y, int64_t n_rows, int64_t row, int l, typename VecF<C>::T v) { store_row_fp8<D, C>(Y, n_rows, row, l, v); }
+};
 __device__ __forceinline__ bool bit_set(const uint32_t *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
 // fixed-point gradient row -> fp32 Gs row:  (float)(q * 2^-50) / (K+1)
@@ -99,6 +157,7 @@ template <int C> __device__ __forceinline__ typename VecF<C>::T loadv_fixed(cons
 }
 
 struct GatherSrc {           // what a row gather reads
+    const float *S;          // fp8 table: its row scales (an entry's weight is multiplied by S[col] when it is staged), else NULL
     const void *X;           // [N,D] of TI; SPARSE: the fp32 copy of the flagged gradient rows (k_g32)
     const uint32_t *bm;      // SPARSE: non-zero-row bitmap (global, or the workgroup's LDS copy)
     float div;               // unused by the gathers (K+1; the epilogues take it from SpmmArgs)
@@ -130,6 +189,23 @@ template <> struct Raw<bf16_t, false> {
         if (BIG) return *reinterpret_cast<const T *>((const bf16_t *)s.X + (int64_t)col * D + l * 8);
         return *reinterpret_cast<const T *>((const char *)s.X + ((uint32_t)col * (uint32_t)(D * 2) + (uint32_t)(l * 16))); }
     static __device__ __forceinline__ f32x8 cvt(const T &r, float) { return __builtin_convertvector(r, f32x8); }
+};
+template <> struct Raw<fp8_t, false> {
+    static constexpr int CPL = 16;
+    typedef u32x4 T;
+    template <bool BIG> static __device__ __forceinline__ T load(const GatherSrc &s, int col, int D, int l) {
+        if (BIG) return *reinterpret_cast<const T *>((const char *)s.X + (int64_t)col * D + l * 16);
+        return *reinterpret_cast<const T *>((const char *)s.X + ((uint32_t)col * (uint32_t)D + (uint32_t)(l * 16))); }
+    // the row scale is NOT applied here: the entry's weight was multiplied by it when the entry was staged
+    static __device__ __forceinline__ f32x16 cvt(const T &r, float) {
+        f32x16 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[i], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[i], true);
+            o[4 * i] = a[0]; o[4 * i + 1] = a[1]; o[4 * i + 2] = b[0]; o[4 * i + 3] = b[1];
+        }
+        return o;
+    }
 };
 // SPARSE: the flagged rows of Gs, converted once per step from the fixed-point accumulator to fp32 by k_g32
 // (gathering the 512-byte int64 rows and converting every gathered copy -- int64 -> fp64 -> fp32 and a
@@ -202,9 +278,6 @@ __device__ __forceinline__ void tile_gather(const int2 *stage, int cnt, const Ga
                                             typename Geo<D, TI, SPARSE>::Acc &acc) {
     constexpr int NPW = Geo<D, TI, SPARSE>::NPW, UMAX = SPARSE ? 4 : UCAP;
     static_assert(4 * NPW <= TILE_PAD, "the padding behind a tile must cover the deepest batch's overshoot");
-#ifdef LGCN_EXP_NO_GATHER
-    return;
-#endif
     cnt = __builtin_amdgcn_readfirstlane(cnt);
     int j = 0;
     if (UMAX >= 8) for (; cnt - j > 4 * NPW; j += 8 * NPW) gather_batch<D, TI, SPARSE, (UMAX >= 8 ? 8 : UMAX), BIG>(stage, j, src, lane, acc);
@@ -268,8 +341,10 @@ row_gather(const ES &es, int64_t start, int64_t end, const GatherSrc &src, int l
     if (start + lane < end) cv = es.at(start + lane);
     for (int64_t base = start; base < end; base += 64) {
         const int n = (int)min((int64_t)64, end - base);
+        if (!SPARSE && src.S) cv.y = __float_as_int(__int_as_float(cv.y) * src.S[cv.x]);     // fp8 table: weight x row scale of the column
         const int cnt = tile_stage<SPARSE>(cv.x, __int_as_float(cv.y), n, src, lane, stage);
         __builtin_amdgcn_wave_barrier();
+        cv = make_int2(0, 0);
         if (base + 64 + lane < end) cv = es.at(base + 64 + lane);
         tile_gather<D, TI, SPARSE, BIG>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
@@ -339,6 +414,7 @@ struct SpmmArgs {
     const float *G32;             // their fp32 copy Gs = G64 / 2^50 / (K+1), valid on the flagged rows (k_g32)
     float *P; float *M; float *V;
     bf16_t *Pb;                   // optional bf16 shadow of P written by the Adam epilogue
+    void *Pq;                     // optional fp8 shadow of P (rows + scales), same
     // last kernel of a step (K >= 2): its epilogue zeroes the G64 rows / bitmap bits it consumes and one
     // wave reduces the per-triplet loss terms, so no separate clean-up launch is needed
     int clear;
@@ -395,8 +471,9 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
         p = p - a.step_size * (m / denom);              // addcdiv_(exp_avg, denom, -step_size)
         storev<C>(a.P + off, p); storev<C>(a.M + off, m); storev<C>(a.V + off, v);
         if (a.Pb) storev<C>(a.Pb + off, p);
+        if (a.Pq) store_row_fp8<D, C>(a.Pq, a.n_rows, row, l, p);
     } else {
-        storev<C>((TO *)a.Y + off, acc);
+        RowStore<D, C, TO>::put(a.Y, a.n_rows, row, l, acc);
     }
 }
 
@@ -514,7 +591,8 @@ template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAV
 #endif
 template <int D, typename TI, bool SP> struct RowGeo {
     static constexpr int NPW = Geo<D, TI, SP>::NPW;
-    static constexpr int WANT = SP ? 1 : (Geo<D, TI, SP>::CPL == 8 ? SPMM_GPR_BF16 : SPMM_GPR_F32);
+    // (an fp8 row is D / 16 lanes wide: NPW / 4 groups per row keep 4 rows per wave at every d)
+    static constexpr int WANT = SP ? 1 : (Geo<D, TI, SP>::CPL == 16 ? (NPW >= 4 ? NPW / 4 : 1) : Geo<D, TI, SP>::CPL == 8 ? SPMM_GPR_BF16 : SPMM_GPR_F32);
     static constexpr int GPR = NPW >= WANT ? WANT : NPW;
     static constexpr int RPK = NPW / GPR;          // rows of a pack
 };
@@ -536,7 +614,8 @@ template <int LPR, int GPR> __device__ __forceinline__ float sum_row_groups(floa
 }
 
 template <int D, typename TI, typename TO, int MODE, bool BIG>
-__global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) == 4) ? SPMM_MIN_WAVES_ADAM : SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
+// (fp8 tables: 16 accumulators per lane and, with Adam, 3 x 16 operands: a 128-register budget, 4 waves per SIMD)
+__global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & M_ADAM) && sizeof(TI) == 4) ? SPMM_MIN_WAVES_ADAM : SPMM_MIN_WAVES) k_spmm(SpmmArgs a) {
     constexpr bool SP = (MODE & M_SPARSE) != 0;
     typedef Geo<D, TI, SP> G;
     typedef typename G::Acc Acc;
@@ -550,12 +629,13 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
     // group of the row); lane groups reading the same position of different rows hit different banks (76 * 2 mod 64 = 24)
     constexpr int ST = 76;
     static_assert(64 + 3 * GPR <= ST, "staged row + padding");
-    constexpr int U = SP ? SPMM_U_SP : SPMM_U;
+    constexpr int U = SP ? SPMM_U_SP : (C == 16 ? 4 : SPMM_U);      // fp8: 16 accumulators per lane; 4 x 16 B in flight per lane
     __shared__ int2 stage_lds[SPMM_WPB][(RPK * ST > TILE_ST ? RPK * ST : TILE_ST)];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GatherSrc src;
     src.X = SP ? (const void *)a.G32 : a.X; src.bm = a.bitmap; src.div = a.div;
+    src.S = (!SP && sizeof(TI) == 1) ? fp8_scales(a.X, a.n_rows, D) : nullptr;
     // (a per-workgroup LDS copy of the row bitmap -- 9 KiB on Gowalla -- was measured: no gain, the copy's
     //  own round trip per workgroup costs what the per-neighbour tests save once a pack's tests are batched)
     // (block 0 is dispatched first: the reduction overlaps the whole launch; on the last block it
@@ -658,6 +738,11 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
         }
         const int myr = g / GPR, sub = g % GPR;      // this lane group's row of the pack, and its share of it
         int maxcnt = 0;
+        if (!SP && sizeof(TI) == 1) {                // fp8 table: weight x row scale of the column (padding entries: column 0, weight 0)
+#pragma unroll
+            for (int it = 0; it < RPK; it++)
+                if (it * 64 < tot) cvr[it].y = __float_as_int(__int_as_float(cvr[it].y) * src.S[cvr[it].x]);
+        }
         if (!SP) {
 #pragma unroll
             for (int it = 0; it < RPK; it++) {
@@ -752,14 +837,23 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, ((MODE & M_ADAM) && sizeof(TI) 
 struct MeanArgs {
     const float *X0; const void *Xl[LGCN_MAX_LAYERS + 1]; int K;
     float *out; int64_t n4;      // number of 4-element pieces
+    int32_t d; int64_t N;        // row width and rows of the tables (fp8 tables: where a piece's row scale lies)
 };
+// piece i (4 consecutive elements) of an [N,d] table of TI
+template <typename TI> __device__ __forceinline__ f32x4 tab_load4(const void *tab, int64_t i, int d, int64_t N) { return load4((const TI *)tab + i * 4); }
+template <> __device__ __forceinline__ f32x4 tab_load4<fp8_t>(const void *tab, int64_t i, int d, int64_t N) {
+    const int w = ((const int *)tab)[i];
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+    const float sc = ((const float *)((const char *)tab + N * d))[(i * 4) / d];
+    return f32x4{a[0] * sc, a[1] * sc, b[0] * sc, b[1] * sc};
+}
 
 template <typename TI>
 __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
     const float div = (float)(a.K + 1);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
         f32x4 s = load4(a.X0 + i * 4);
-        for (int k = 1; k < a.K; k++) s += load4((const TI *)a.Xl[k] + i * 4);
+        for (int k = 1; k < a.K; k++) s += tab_load4<TI>(a.Xl[k], i, a.d, a.N);
         s += load4(a.out + i * 4);
         store4(a.out + i * 4, s / div);
     }
@@ -771,6 +865,31 @@ __global__ void __launch_bounds__(256) k_layer_mean(MeanArgs a) {
 __global__ void __launch_bounds__(256) k_to_bf16(const float *src, bf16_t *dst, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
         store4(dst + i * 4, load4(src + i * 4));
+}
+// fp8 copy of an fp32 table (rows + row scales): the input of layer 1 with fp8 activation storage.  One lane group of
+// d / 16 lanes per row (64 B read, 16 B written per lane).
+template <int D>
+__global__ void __launch_bounds__(256) k_to_fp8(const float *src, void *dst, int64_t n_rows) {
+    constexpr int LPR = D / 16, RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t rows_pad = (n_rows + RPB - 1) / RPB * RPB;          // whole lane groups stay together (the shuffles need them)
+    for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < rows_pad; r += (int64_t)gridDim.x * RPB) {
+        const int64_t row = r < n_rows ? r : n_rows - 1;
+        const f32x16 v = loadv<16>(src + row * D + l * 16);
+        if (r < n_rows) store_row_fp8<D, 16>(dst, n_rows, row, l, v);
+        else { float amax = 0.f; for (int o = 1; o < LPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o)); }   // (keep the group's shuffles matched)
+    }
+}
+static int launch_to_fp8(const float *src, void *dst, int64_t n_rows, int d, hipStream_t st) {
+    const int64_t blocks = (n_rows * (d / 16) + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192);
+    switch (d) {
+    case 64: hipLaunchKernelGGL((k_to_fp8<64>), dim3(grid), dim3(256), 0, st, src, dst, n_rows); return 0;
+    case 128: hipLaunchKernelGGL((k_to_fp8<128>), dim3(grid), dim3(256), 0, st, src, dst, n_rows); return 0;
+    case 256: hipLaunchKernelGGL((k_to_fp8<256>), dim3(grid), dim3(256), 0, st, src, dst, n_rows); return 0;
+    }
+    lgcn_set_error("fp8 storage needs an embedding dim of 64, 128 or 256");
+    return 3;
 }
 static void launch_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t st) {
     const int64_t n4 = n / 4, blocks = (n4 + 255) / 256;
@@ -814,6 +933,10 @@ struct BprArgs {
     int32_t dense_last;   // X_K exists densely (Xl[K]): the slot rows are read, not gathered
     int32_t reg_ego;      // L2 term on the tables' own rows X0[row] (upstream LightGCN) instead of the propagated rows (the fork)
     int32_t *cnt;         // reg_ego: per-row count of the batch slots naming the row (bumped where the row is flagged), or NULL
+    // column-sharded data parallelism: this rank holds D of the table's columns.  cols_phase 1: the batch-row kernel stops after
+    // the slot rows -- it writes them to erows [3][B_local][D] and the PARTIAL dot products / squared norms over its columns to
+    // colsum [3][B_local] (pos score, neg score, reg term); the ranks all-reduce colsum; k_cols_finish does the rest.
+    int32_t cols_phase; float *erows; float *colsum;
 };
 
 __device__ __forceinline__ float logsigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
@@ -833,6 +956,9 @@ __device__ __forceinline__ bool triplet_bad(const BprArgs &a, int b) {
 // at a 32-byte stride and cost 9 of a 13.7 us kernel.)  x = e_u.e_p - e_u.e_n ; l = logsigmoid(x) ;
 // r = |e_u|^2+|e_p|^2+|e_n|^2 ; gradient rows w.r.t. the propagated table -> fixed-point
 // atomics into G64 + row flags (single GPU / dense DP) or the exchange block (DP rows).
+template <int D>
+__device__ __forceinline__ void triplet_finish(const BprArgs &a, int b, int l, const float *u, const float *p, const float *n,
+                                               float ps, float ns, float rr);
 // reg_ego: u0 / p0 / n0 = the slots' rows of the table itself; the L2 term is theirs and its gradient never enters G
 // (the Adam epilogue adds it from the slot counts), so the gradient rows carry no lam term.
 template <int D>
@@ -853,6 +979,26 @@ __device__ __forceinline__ void triplet_loss_regs(const BprArgs &a, int b, int l
     for (int off = 1; off < LPT; off <<= 1) {
         ps += __shfl_xor(ps, off); ns += __shfl_xor(ns, off); rr += __shfl_xor(rr, off);
     }
+    if (a.cols_phase == 1) {                    // column shard: rows + partial sums out, the all-reduce comes next
+        const bool bad1 = triplet_bad(a, b);
+        if (l == 0) { a.colsum[b] = bad1 ? 0.f : ps; a.colsum[a.B_local + b] = bad1 ? 0.f : ns; a.colsum[2 * a.B_local + b] = bad1 ? 0.f : rr; }
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            a.erows[((int64_t)0 * a.B_local + b) * D + j * LPT + l] = u[j];
+            a.erows[((int64_t)1 * a.B_local + b) * D + j * LPT + l] = p[j];
+            a.erows[((int64_t)2 * a.B_local + b) * D + j * LPT + l] = n[j];
+        }
+        return;
+    }
+    triplet_finish<D>(a, b, l, u, p, n, ps, ns, rr);
+}
+
+// loss terms + the three gradient rows of one triplet from its slot rows and its (complete) dot products
+template <int D>
+__device__ __forceinline__ void triplet_finish(const BprArgs &a, int b, int l, const float *u, const float *p, const float *n,
+                                               float ps, float ns, float rr) {
+    constexpr int LPT = D < 64 ? D : 64, CPL = D / LPT;
+    const float lam = a.reg_ego ? 0.f : a.lam;
     const bool tbad = triplet_bad(a, b);        // an out-of-range id voids the whole triplet
     const float x = ps - ns;
     const float gb = tbad ? 0.f : -a.inv_B * sigmoid_neg_f(x);
@@ -916,11 +1062,13 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
     int2 cv = make_int2(0, 0);
     if (t * 64 + lane < n) cv = es.at(start + t * 64 + lane);
     for (;;) {
+        if (src.S) cv.y = __float_as_int(__int_as_float(cv.y) * src.S[cv.x]);      // fp8 table: weight x row scale of the column
         const int cnt = tile_stage<false>(cv.x, __int_as_float(cv.y), min(64, n - t * 64), src, lane, stage);
         __builtin_amdgcn_wave_barrier();
         int tn = t + 1;
         if (tn % UT == 0) tn += 3 * UT;
         const bool more = tn < ntiles;
+        cv = make_int2(0, 0);
         if (more && tn * 64 + lane < n) cv = es.at(start + tn * 64 + lane);
         tile_gather<D, TG, false, BIG, TRIPLET_U>(stage, cnt, src, lane, acc);
         __builtin_amdgcn_wave_barrier();
@@ -955,12 +1103,13 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
                 const int col = j * LPT + lane;
                 float s = a.X0[row * D + col];
                 if (a.reg_ego) ego[c][col] = s;
-                for (int k = 1; k < a.K; k++) s += (float)((const TI *)a.Xl[k])[row * D + col];
+                for (int k = 1; k < a.K; k++) s += tab_elem<TI>(a.Xl[k], a.N, D, row, col);
                 base[c][col] = s;
             }
         }
     }
     GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
+    src.S = sizeof(TG) == 1 ? fp8_scales(Xg, a.N, D) : nullptr;
     tile_pad_init(stage, threadIdx.x & 63);
     bool any = (w == 0 || w == 3);
 #pragma unroll 1
@@ -1043,11 +1192,26 @@ __global__ void __launch_bounds__(256) k_triplet_dense(BprArgs a) {
             const int64_t o = rows[c] * D + j * LPT + l;
             float s = a.X0[o];
             e0[c][j] = s;
-            for (int k = 1; k <= a.K; k++) s += (float)((const TI *)a.Xl[k])[o];
+            for (int k = 1; k <= a.K; k++) s += tab_elem<TI>(a.Xl[k], a.N, D, rows[c], j * LPT + l);
             e[c][j] = s / div;
         }
     }
     triplet_loss_regs<D>(a, b, l, e[0], e[1], e[2], e0[0], e0[1], e0[2]);
+}
+
+// Column-sharded step, after the all-reduce of the partial sums: one lane group per triplet reads its three slot rows (this rank's
+// columns) and the COMPLETE scores / reg term, writes the loss terms and scatters the gradient rows of its columns.
+template <int D>
+__global__ void __launch_bounds__(256) k_cols_finish(BprArgs a) {
+    constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT, TPB = 256 / LPT;
+    const int b = blockIdx.x * TPB + threadIdx.x / LPT, l = threadIdx.x % LPT;
+    if (b >= a.B_local) return;
+    float e[3][CPT];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int j = 0; j < CPT; j++) e[c][j] = a.erows[((int64_t)c * a.B_local + b) * D + j * LPT + l];
+    triplet_finish<D>(a, b, l, e[0], e[1], e[2], a.colsum[b], a.colsum[a.B_local + b], a.colsum[2 * a.B_local + b]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1474,6 +1638,16 @@ template <int D, int MODE>
 static int launch_spmm_d(const SpmmArgs &a, int x_dtype, int y_dtype, hipStream_t st) {
     if (MODE & M_SPARSE) x_dtype = LGCN_F32;           // source is the fixed-point table; TI unused
     if (MODE & M_ADAM) y_dtype = LGCN_F32;
+    if (x_dtype == LGCN_FP8 || y_dtype == LGCN_FP8) {
+        // fp8 tables: 16 elements per lane, so d >= 64; fp8 <-> bf16 conversions are not instantiated
+        if constexpr (D >= 64) {
+            if (x_dtype == LGCN_FP8 && y_dtype == LGCN_FP8) { launch_spmm_t<D, fp8_t, fp8_t, MODE>(a, st); return 0; }
+            if (x_dtype == LGCN_FP8 && y_dtype == LGCN_F32) { launch_spmm_t<D, fp8_t, float, MODE>(a, st); return 0; }
+            if (x_dtype == LGCN_F32 && y_dtype == LGCN_FP8) { launch_spmm_t<D, float, fp8_t, MODE>(a, st); return 0; }
+        }
+        lgcn_set_error("fp8 tables: embedding dim 64, 128 or 256, and fp8 <-> fp32 only (no fp8 <-> bf16 launch)");
+        return 3;
+    }
     if (x_dtype == LGCN_F32 && y_dtype == LGCN_F32) launch_spmm_t<D, float, float, MODE>(a, st);
     else if (x_dtype == LGCN_F32 && y_dtype == LGCN_BF16) launch_spmm_t<D, float, bf16_t, MODE>(a, st);
     else if (x_dtype == LGCN_BF16 && y_dtype == LGCN_F32) launch_spmm_t<D, bf16_t, float, MODE>(a, st);
@@ -1515,7 +1689,7 @@ static int launch_spmm_addself(const SpmmArgs &a, int d, hipStream_t st) {
     }
 
 static int check_dtype(int t) {
-    if (t != LGCN_F32 && t != LGCN_BF16) { lgcn_set_error("dtype must be LGCN_F32 or LGCN_BF16"); return 3; }
+    if (t != LGCN_F32 && t != LGCN_BF16 && t != LGCN_FP8) { lgcn_set_error("dtype must be LGCN_F32, LGCN_BF16 or LGCN_FP8"); return 3; }
     return 0;
 }
 
@@ -1772,7 +1946,19 @@ extern "C" int lgcn_spmm_csr(const lgcn_graph *g, const void *X, int x_dtype, vo
     return 0;
 }
 
-static inline size_t esize(int dtype) { return dtype == LGCN_BF16 ? 2 : 4; }
+// bytes of one [N,d] table of a storage type (fp8: rows + fp32 row scales, padded so that the next table stays 256-byte aligned)
+static inline size_t table_bytes(int64_t N, int d, int dtype) {
+    if (dtype == LGCN_FP8) return (((size_t)N * d + (size_t)N * 4) + 255) & ~(size_t)255;
+    return (size_t)N * d * (dtype == LGCN_BF16 ? 2 : 4);
+}
+extern "C" int64_t lgcn_table_bytes(int64_t n_rows, int32_t d, int32_t dtype) { return n_rows > 0 && d > 0 ? (int64_t)table_bytes(n_rows, d, dtype) : 0; }
+extern "C" int lgcn_to_fp8(const float *src, void *dst, int64_t n_rows, int32_t d, void *stream) {
+    if (!src || !dst || n_rows <= 0) { lgcn_set_error("lgcn_to_fp8: invalid argument"); return 3; }
+    int rc = launch_to_fp8(src, dst, n_rows, d, (hipStream_t)stream);
+    if (rc) return rc;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, int d, int act_dtype, void *work,
                                    float *out, void *stream) {
@@ -1784,14 +1970,19 @@ extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, 
     { int rc0 = graph_acquire(g, st); if (rc0) return rc0; }
     const int64_t N = g->n_rows;
     MeanArgs m{};
-    m.X0 = E0; m.K = K; m.out = out; m.n4 = N * d / 4;
-    const size_t stride = (size_t)N * d * esize(act_dtype);
+    m.X0 = E0; m.K = K; m.out = out; m.n4 = N * d / 4; m.d = d; m.N = N;
+    const size_t stride = table_bytes(N, d, act_dtype);
     const void *prev = E0; int prev_dtype = LGCN_F32;
     if (act_dtype == LGCN_BF16 && K >= 2) {
         // the same rule as the training step: with bf16 activation storage layer 1 reads bf16(E0).  `out` is free until
         // the last layer writes it (K >= 2): its memory holds the 2-byte copy meanwhile
         launch_to_bf16(E0, (bf16_t *)out, N * d, st);
         prev = out; prev_dtype = LGCN_BF16;
+    }
+    if (act_dtype == LGCN_FP8 && K >= 2) {                 // the same with fp8 storage: rows + scales fit the fp32 `out`
+        int rc = launch_to_fp8(E0, out, N, d, st);
+        if (rc) return rc;
+        prev = out; prev_dtype = LGCN_FP8;
     }
     for (int k = 1; k <= K; k++) {
         const bool last = (k == K);
@@ -1805,7 +1996,8 @@ extern "C" int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, 
     const int64_t blocks = (m.n4 + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
     if (act_dtype == LGCN_F32) hipLaunchKernelGGL((k_layer_mean<float>), dim3(grid), dim3(256), 0, st, m);
-    else hipLaunchKernelGGL((k_layer_mean<bf16_t>), dim3(grid), dim3(256), 0, st, m);
+    else if (act_dtype == LGCN_BF16) hipLaunchKernelGGL((k_layer_mean<bf16_t>), dim3(grid), dim3(256), 0, st, m);
+    else hipLaunchKernelGGL((k_layer_mean<fp8_t>), dim3(grid), dim3(256), 0, st, m);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1833,6 +2025,7 @@ struct lgcn_ctx {
     int fwd_layers;               // dense forward layers per step: K-1, or K with dense_last
     float *g32;                   // [N,d] fp32 copy of the step's flagged gradient rows (library-owned; k_g32)
     bf16_t *e0b;                  // [N,d] bf16 copy of E0 (library-owned; bf16 activation storage with K >= 2 only)
+    void *e0q;                    // fp8 copy of E0, rows + scales (library-owned; fp8 activation storage with K >= 2 only); e0b_fresh covers it too
     bool e0b_fresh;               // e0b == bf16(E0) right now (set by the Adam epilogue inside a multi-step call)
     bool in_loop;                 // inside lgcn_train_epoch / lgcn_train_epoch_dp: the Adam epilogue keeps e0b current
     lgcn_graph *hub_graph;        // plan over the rows with more than hub_nnz non-zeros (or NULL): their last-layer rows are
@@ -1847,6 +2040,7 @@ struct lgcn_ctx {
     long long *gate_partials;     // [n_wg, P] parameter-gradient partial sums, fixed point (library-owned)
     int32_t gate_P, gate_wgs;
     int32_t *cnt;                 // reg_ego: [N] slots of the running step naming each row (library-owned, zero between steps)
+    float *colsum;                // [3 * max_batch] partial scores / reg terms of a column-sharded step (library-owned)
 };
 // a multi-step call: nobody but this library touches E0 between its steps
 struct LoopScope {
@@ -1864,6 +2058,8 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if ((c.K > 1 || c.dense_last) && !c.act) { lgcn_set_error("lgcn_ctx_create: activation workspace missing"); return 3; }
     if (c.d != 32 && c.d != 64 && c.d != 128 && c.d != 256) { lgcn_set_error("embedding dim must be 32, 64, 128 or 256"); return 3; }
     if (check_dtype(c.act_dtype)) return 3;
+    if (c.act_dtype == LGCN_FP8 && c.d < 64) { lgcn_set_error("lgcn_ctx_create: fp8 activation storage needs an embedding dim of 64, 128 or 256"); return 3; }
+    if (c.act_dtype == LGCN_FP8 && (c.item_pop || c.i2i)) { lgcn_set_error("lgcn_ctx_create: fp8 activation storage is implemented for the default model, not with the optional branches"); return 3; }
     if (c.n_users <= 0 || c.n_users >= c.graph->n_rows || c.max_batch <= 0) { lgcn_set_error("lgcn_ctx_create: bad sizes"); return 3; }
     if (c.d > c.graph->d_max) { lgcn_set_error("lgcn_ctx_create: d exceeds the graph's d_max"); return 3; }
     const bool gate = c.item_pop != nullptr, smooth = c.i2i != nullptr;
@@ -1879,18 +2075,19 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (c.reg_ego && (gate || smooth)) { lgcn_set_error("lgcn_ctx_create: reg_ego (upstream's L2 term) is defined for the default model only, not with the optional branches"); return 3; }
     lgcn_ctx *x = new (std::nothrow) lgcn_ctx;
     if (!x) { lgcn_set_error("out of memory"); return 4; }
-    x->c = c; x->step = 0; x->N = c.graph->n_rows; x->cnt = nullptr;
+    x->c = c; x->step = 0; x->N = c.graph->n_rows; x->cnt = nullptr; x->colsum = nullptr;
     x->bm_words = (x->N + 31) / 32; x->flip = 0;
-    const size_t stride = (size_t)x->N * c.d * esize(c.act_dtype);
+    const size_t stride = table_bytes(x->N, c.d, c.act_dtype);
     for (int k = 0; k <= LGCN_MAX_LAYERS; k++) x->act[k] = nullptr;
     x->fwd_layers = c.dense_last ? c.K : c.K - 1;
     for (int k = 1; k <= x->fwd_layers; k++) x->act[k] = (char *)c.act + (size_t)(k - 1) * stride;
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
-    x->g32 = nullptr; x->e0b = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
+    x->g32 = nullptr; x->e0b = nullptr; x->e0q = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
     x->hub_graph = nullptr; x->hub_nnz = 0; x->hub_rows = 0;
     x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_P = 0; x->gate_wgs = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&x->colsum, sizeof(float) * 3 * (size_t)c.max_batch) == hipSuccess;
     if (ok && c.reg_ego) ok = hipMalloc((void **)&x->cnt, sizeof(int32_t) * (size_t)x->N) == hipSuccess && hipMemset(x->cnt, 0, sizeof(int32_t) * (size_t)x->N) == hipSuccess;
     if (ok && x->variant) ok = hipMalloc((void **)&x->tvar, gbytes) == hipSuccess;
     if (ok && smooth) {
@@ -1903,6 +2100,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
         ok = hipMalloc((void **)&x->gate_partials, sizeof(long long) * (size_t)x->gate_wgs * x->gate_P) == hipSuccess;
     }
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
+    if (ok && c.act_dtype == LGCN_FP8 && c.K >= 2) ok = hipMalloc(&x->e0q, table_bytes(x->N, c.d, LGCN_FP8)) == hipSuccess;
     if (ok && !c.dense_last) {
         // Rows too long for one workgroup (a 800 000-neighbour item of the 10M x 1M graph kept ONE k_triplet workgroup busy
         // for 37 ms, several times per batch): a plan over just those rows; k_spmm computes their last-layer rows for
@@ -1926,11 +2124,13 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     }
     if (!ok) {
         if (x->g32) (void)hipFree(x->g32);
+        if (x->colsum) (void)hipFree(x->colsum);
         if (x->cnt) (void)hipFree(x->cnt);
         if (x->tvar) (void)hipFree(x->tvar);
         if (x->item_bitmap) (void)hipFree(x->item_bitmap);
         if (x->gate_partials) (void)hipFree(x->gate_partials);
         if (x->e0b) (void)hipFree(x->e0b);
+        if (x->e0q) (void)hipFree(x->e0q);
         if (x->hub_graph) lgcn_graph_destroy(x->hub_graph);
         delete x;
         lgcn_set_error("lgcn_ctx_create: cannot allocate the library-owned tables (N*d*4 bytes fp32 gradient rows, N*d*2 bf16 parameters)");
@@ -1942,11 +2142,13 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
 extern "C" void lgcn_ctx_destroy(lgcn_ctx *ctx) {
     if (!ctx) return;
     if (ctx->g32) (void)hipFree(ctx->g32);
+    if (ctx->colsum) (void)hipFree(ctx->colsum);
     if (ctx->cnt) (void)hipFree(ctx->cnt);
     if (ctx->tvar) (void)hipFree(ctx->tvar);
     if (ctx->item_bitmap) (void)hipFree(ctx->item_bitmap);
     if (ctx->gate_partials) (void)hipFree(ctx->gate_partials);
     if (ctx->e0b) (void)hipFree(ctx->e0b);
+    if (ctx->e0q) (void)hipFree(ctx->e0q);
     if (ctx->hub_graph) lgcn_graph_destroy(ctx->hub_graph);
     delete ctx;
 }
@@ -1978,6 +2180,12 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
         x->e0b_fresh = true;
         prev = x->e0b; prev_dt = LGCN_BF16;
     }
+    if (x->e0q && x->fwd_layers >= 1) {                 // fp8 activation storage: layer 1 gathers fp8(E0)
+        if (!x->in_loop) x->e0b_fresh = false;
+        if (!x->e0b_fresh) { int rc = launch_to_fp8(c.E0, x->e0q, x->N, c.d, st); if (rc) return rc; }
+        x->e0b_fresh = true;
+        prev = x->e0q; prev_dt = LGCN_FP8;
+    }
     for (int k = 1; k <= x->fwd_layers; k++) {
         SpmmArgs a = base_spmm(x);
         a.X = prev; a.Y = x->act[k];
@@ -1990,10 +2198,11 @@ static int run_forward(lgcn_ctx *x, hipStream_t st) {
 
 static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
                    int32_t B_global, int32_t b_off, int32_t B_local, int32_t shard, bool atomics, bool exchange, hipStream_t st,
-                   bool count_slots = true) {
+                   bool count_slots = true, int cols_phase = 0) {
     const lgcn_train_config &c = x->c;
     BprArgs a{};
     a.reg_ego = c.reg_ego; a.cnt = (atomics && count_slots) ? x->cnt : nullptr;
+    a.cols_phase = cols_phase; a.erows = c.contrib; a.colsum = x->colsum;
     a.indptr = c.graph->indptr; a.indices = c.graph->indices; a.vals = c.graph->vals; a.X0 = c.E0; a.K = c.K;
     for (int k = 1; k <= x->fwd_layers; k++) a.Xl[k] = x->act[k];
     a.dense_last = c.dense_last;
@@ -2005,6 +2214,14 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
     a.stale_bitmap = c.bitmap + (x->flip ^ 1) * x->bm_words; a.bitmap_words = x->bm_words;
     a.contrib = c.contrib; a.terms = c.terms; a.err = c.err; a.exchange = exchange ? 1 : 0;
     a.terms_off = exchange ? 0 : b_off; a.terms_stride = B_global;
+    if (cols_phase == 2) {      // column shard, after the all-reduce: loss terms + gradient scatter from the stored slot rows
+        if (B_local <= 0) return 0;
+        DISPATCH_D(c.d, {
+            const int tpb = 256 / (D < 64 ? D : 64);
+            hipLaunchKernelGGL((k_cols_finish<D>), dim3((unsigned)((B_local + tpb - 1) / tpb)), dim3(256), 0, st, a);
+        });
+        return 0;
+    }
     if (x->hub_graph && !c.dense_last && B_local > 0) {
         // last layer of the hub rows, X_K[hub] = (A_hat X_{K-1})[hub] in fp32, into the library's [N,d] table (free until k_g32)
         { int rc0 = graph_acquire(x->hub_graph, st); if (rc0) return rc0; }
@@ -2021,7 +2238,15 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
         return 0;
     }
     DISPATCH_D(c.d, {
-        if (c.dense_last) {
+        if (c.act_dtype == LGCN_FP8) {
+            if constexpr (D >= 64) {
+                if (c.dense_last) {
+                    const int tpb = 256 / 64;
+                    hipLaunchKernelGGL((k_triplet_dense<D, fp8_t>), dim3((unsigned)((B_local + tpb - 1) / tpb)), dim3(256), 0, st, a);
+                } else if (big_table(x->N, D)) hipLaunchKernelGGL((k_triplet<D, fp8_t, true>), dim3(B_local), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_triplet<D, fp8_t, false>), dim3(B_local), dim3(256), 0, st, a);
+            }
+        } else if (c.dense_last) {
             const int tpb = 256 / (D < 64 ? D : 64);
             const unsigned gd = (unsigned)((B_local + tpb - 1) / tpb);
             if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
@@ -2189,7 +2414,8 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
         // inside a multi-step call on replicated tables the epilogue keeps the bf16 copy of E0 current (row-sharded steps
         // update only the owned rows and convert again after the exchange)
         a.Pb = (x->e0b && x->in_loop && fused_finish) ? x->e0b : nullptr;
-        x->e0b_fresh = a.Pb != nullptr;
+        a.Pq = (x->e0q && x->in_loop && fused_finish) ? x->e0q : nullptr;
+        x->e0b_fresh = a.Pb != nullptr || a.Pq != nullptr;
         a.step_size = (float)(c.lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
         a.w1 = (float)(1.0 - c.beta1); a.beta2 = (float)c.beta2; a.omb2 = (float)(1.0 - c.beta2); a.eps = (float)c.eps;
         if (!first && fused_finish) {       // K >= 2: this launch also cleans the workspace and reduces the loss
@@ -2338,6 +2564,40 @@ extern "C" int lgcn_train_step_dp_part2(lgcn_ctx *x, const int32_t *users, const
 }
 
 // ---------------------------------------------------------------------------------
+// Column-sharded data parallelism: rank r holds columns [r d/W, (r+1) d/W) of E0, of the Adam state and of every activation --
+// its context is an ordinary context of width d / W over the same graph.  Propagation, the gradient scatter, the backward
+// chain and Adam are independent per column; the one thing that is not is the score of a triplet, a dot product over ALL
+// columns.  So the step is: part 1 (forward + slot rows + PARTIAL scores / reg terms of this rank's columns), ONE all-reduce
+// of 3 B floats, part 2 (loss terms, gradient rows of this rank's columns, backward, Adam).  Per-rank SpMM work falls with
+// the world size (rows of d / W elements), which batch sharding cannot offer.  Not bitwise equal to the single-GPU step: the
+// dot products are summed in another order (W partial sums); everything else is.
+// ---------------------------------------------------------------------------------
+extern "C" int lgcn_train_step_cols_part1(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                                          int32_t B, float **partials, void *stream) {
+    int rc = check_batch(x, users, pos, neg, B);
+    if (rc) return rc;
+    if (x->variant) { lgcn_set_error("column-sharded step: the popularity gate / item-item smoothing mix columns (MLPs over the row): not supported"); return 3; }
+    if (!x->c.contrib) { lgcn_set_error("column-sharded step: cfg.contrib (3*max_batch*d floats: the batch's slot rows) missing"); return 3; }
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_forward(x, st))) return rc;
+    if ((rc = run_bpr(x, users, pos, neg, B, 0, B, B, false, false, st, false, 1))) return rc;
+    if (partials) *partials = x->colsum;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int lgcn_train_step_cols_part2(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                                          int32_t B, float *loss_out, void *stream) {
+    int rc = check_batch(x, users, pos, neg, B);
+    if (rc) return rc;
+    if (!loss_out) { lgcn_set_error("column-sharded step part 2: loss_out is null"); return 3; }
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_bpr(x, users, pos, neg, B, 0, B, B, true, false, st, true, 2))) return rc;
+    if ((rc = run_backward(x, users, pos, neg, B, nullptr, B, 1, loss_out, st))) return rc;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // Row-sharded propagation (SURVEY 8e "beyond the contract"; the analogue of the reference's A_split
 // row folds, dataloader.py:192-201): the context's graph plan holds only the rows this rank owns; a
 // phase computes those rows of one layer, and the owners' rows are exchanged before the next phase.
@@ -2347,6 +2607,7 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
     if (x->variant) { lgcn_set_error("lgcn_rs_phase: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
+    if (x->c.act_dtype == LGCN_FP8) { lgcn_set_error("lgcn_rs_phase: row-sharded propagation exchanges fp32 / bf16 rows; fp8 activation storage (rows + row scales) is not wired into the exchange"); return 3; }
     const lgcn_train_config &c = x->c;
     hipStream_t st = (hipStream_t)stream;
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("lgcn_rs_phase: bad world/rank"); return 3; }
@@ -2429,9 +2690,9 @@ static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, c
                                int64_t T, int32_t B_global, int32_t reduce, const int64_t *row_ranges, float *gathered,
                                float *loss_out, void *stream) {
     if (!x || !dp || !users || !pos || !neg || !loss_out) { lgcn_set_error("lgcn_train_epoch_dp: null argument"); return 3; }
-    if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE && reduce != LGCN_DP_ROW_SHARDED) { lgcn_set_error("lgcn_train_epoch_dp: unknown reduce mode"); return 3; }
+    if (reduce != LGCN_DP_ROWS && reduce != LGCN_DP_DENSE && reduce != LGCN_DP_ROW_SHARDED && reduce != LGCN_DP_COLS) { lgcn_set_error("lgcn_train_epoch_dp: unknown reduce mode"); return 3; }
     if (reduce == LGCN_DP_ROW_SHARDED && !row_ranges) { lgcn_set_error("lgcn_train_epoch_dp: row_ranges missing"); return 3; }
-    if (reduce != LGCN_DP_DENSE && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
+    if (reduce != LGCN_DP_DENSE && reduce != LGCN_DP_COLS && !gathered) { lgcn_set_error("lgcn_train_epoch_dp: gathered workspace missing"); return 3; }
     if (B_global <= 0 || B_global > x->c.max_batch) { lgcn_set_error("lgcn_train_epoch_dp: batch size out of range"); return 3; }
     const RcclApi *api = dp->api;             // RCCL, or the in-process loopback of the tests
     if (!api) { lgcn_set_error("lgcn_train_epoch_dp: communicator without collectives"); return 12; }
@@ -2448,7 +2709,12 @@ static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, c
         const int32_t b = (int32_t)((T - t) < B_global ? (T - t) : B_global);
         int rc;
         ncclResult_t r;
-        if (reduce == LGCN_DP_ROW_SHARDED) {
+        if (reduce == LGCN_DP_COLS) {
+            if ((rc = lgcn_train_step_cols_part1(x, users + t, pos + t, neg + t, b, nullptr, stream))) return rc;
+            r = api->AllReduce(x->colsum, x->colsum, (size_t)3 * b, ncclFloat32, ncclSum, dp->comm, st);
+            if (r != ncclSuccess) { lgcn_set_error("ncclAllReduce failed"); return 11; }
+            if ((rc = lgcn_train_step_cols_part2(x, users + t, pos + t, neg + t, b, loss_out + 3 * i, stream))) return rc;
+        } else if (reduce == LGCN_DP_ROW_SHARDED) {
             const int32_t K = x->c.K, d = x->c.d;
             const int32_t *u = users + t, *p = pos + t, *n = neg + t;
             void *buf; int32_t dt;

@@ -28,7 +28,15 @@ from . import _lib
 
 
 def _act_code(name):
-    return {'fp32': _lib.F32, 'bf16': _lib.BF16}[name]
+    return {'fp32': _lib.F32, 'bf16': _lib.BF16, 'fp8': _lib.FP8}[name]
+
+
+def _act_tables(n_tables, N, d, act_dtype, dev):
+    """workspace of n_tables [N,d] tables of a storage type, as one tensor whose leading index is the table (fp8 tables
+    are byte blobs: rows + row scales, lgcn_table_bytes each)"""
+    if act_dtype == _lib.FP8:
+        return torch.zeros(n_tables, int(_lib.load().lgcn_table_bytes(N, d, _lib.FP8)), dtype=torch.uint8, device=dev)
+    return torch.zeros(n_tables, N, d, dtype=torch.float32 if act_dtype == _lib.F32 else torch.bfloat16, device=dev)
 
 
 class _Propagate(torch.autograd.Function):
@@ -289,7 +297,6 @@ class LightGCN(nn.Module):
             st['ctx'] = None
         N, d, K = self.n_users + self.m_items, self.latent_dim, self.n_layers
         act_dtype = _act_code(self.config.get('act_dtype', 'fp32'))
-        tdt = torch.float32 if act_dtype == _lib.F32 else torch.bfloat16
         if 'adam_m' not in st:
             st['adam_m'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
             st['adam_v'] = torch.zeros(N, d, dtype=torch.float32, device=dev)
@@ -297,7 +304,7 @@ class LightGCN(nn.Module):
         variants = self.fused_variants
         if variants:
             dense_last = True       # the optional branches score on the layer mean of EVERY row (model.py:221-229)
-        st['act'] = torch.zeros(max(1, K if dense_last else K - 1), N, d, dtype=tdt, device=dev)
+        st['act'] = _act_tables(max(1, K if dense_last else K - 1), N, d, act_dtype, dev)
         st['G64'] = torch.zeros(N, d, dtype=torch.int64, device=dev)
         st['bitmap'] = torch.zeros(2 * ((N + 31) // 32), dtype=torch.int32, device=dev)
         st['terms'] = torch.zeros(3 * max_batch, dtype=torch.float32, device=dev)
@@ -408,10 +415,10 @@ class LightGCN(nn.Module):
         st = self._state()
         N, d, K = self.n_users + self.m_items, self.latent_dim, self.n_layers
         act_dtype = _act_code(self.config.get('act_dtype', 'fp32'))
-        tdt = torch.float32 if act_dtype == _lib.F32 else torch.bfloat16
         work = st.get('eval_work')
-        if K > 1 and (work is None or work.dtype != tdt):
-            work = st['eval_work'] = torch.empty(K - 1, N, d, dtype=tdt, device=self._table.device)
+        if K > 1 and (work is None or st.get('eval_work_dtype') != act_dtype):
+            work = st['eval_work'] = _act_tables(K - 1, N, d, act_dtype, self._table.device)
+            st['eval_work_dtype'] = act_dtype
         out = torch.empty(N, d, dtype=torch.float32, device=self._table.device)
         _lib.check(_lib.load().lgcn_propagate_mean(
             st['graph'].handle, _lib.tp(self._table), K, d, act_dtype, _lib.tp(work) if K > 1 else None,

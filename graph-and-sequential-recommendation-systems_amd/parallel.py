@@ -15,6 +15,10 @@ exchange those rows BEFORE backward propagation instead of all-reducing a dense
     all ranks: order-independent fixed-point reduction of all 3B rows, backward
                propagation, Adam -- bitwise identical on every rank and to the
                single-GPU step, so replicas never drift and need no parameter sync.
+`shard='cols'` shards the COLUMNS of the tables instead of the batch (column_shard below): propagation, gradient
+scatter, backward and Adam are independent per column, so a rank's SpMM work falls with the world size -- the one mode
+in which it does at Gowalla / Amazon-Book size -- and the step needs ONE all-reduce of 3*B floats (the triplets' partial
+scores and reg terms).  Not bitwise equal to one GPU: the dot products are summed as W partial sums.
 `reduce='dense'` is the literal north_star wording -- RCCL all-reduce (SUM) of the
 gradient table, here the fixed-point G64 [N,d] int64, plus SUM of the loss terms (every
 rank flags the rows of the whole batch itself) -- kept as an alternative: also bitwise exact, but N*d*8 bytes
@@ -68,6 +72,39 @@ def owned_rows(ranges, rank):
     return np.concatenate([np.arange(u_lo, u_hi, dtype=np.int32), np.arange(i_lo, i_hi, dtype=np.int32)])
 
 
+def column_range(d, world, rank):
+    """[lo, hi) of the embedding columns rank `rank` holds under shard='cols' (d / world each; the kernels take 32/64/128/256)."""
+    if d % world or (d // world) not in (32, 64, 128, 256):
+        raise ValueError(f"column sharding needs d / world in (32, 64, 128, 256); got d={d}, world={world}")
+    w = d // world
+    return rank * w, (rank + 1) * w
+
+
+def column_shard(model_cls, config, dataset, world, rank, device):
+    """This rank's column slice of the model the single-GPU run would create: the FULL table is initialised exactly as
+    LightGCN.__init__ does (same seed, same draw: model.py:57-63), then columns [lo, hi) become a LightGCN of width d / world.
+    -> the sharded model (its config is a copy with latent_dim_rec = d / world)."""
+    d = int(config['latent_dim_rec'])
+    lo, hi = column_range(d, world, rank)
+    full = model_cls(config, dataset).to(device)
+    cfg = dict(config)
+    cfg['latent_dim_rec'] = hi - lo
+    part = model_cls(cfg, dataset).to(device)
+    with torch.no_grad():
+        part._table.copy_(full._table[:, lo:hi])
+    full._drop_device_state()
+    del full
+    part.col_range = (lo, hi, d)
+    return part
+
+
+class _DevArray:
+    """a device float32 buffer the library owns, as something torch.as_tensor can wrap (no copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
 def exchange_rows(buf, ranges, group=None):
     """The exchange after a row-sharded layer: every owner broadcasts its two row ranges of `buf`
     [N,d] in place (torch.distributed form, used on CPU tensors over gloo in the tests; on the GPU the
@@ -97,6 +134,8 @@ class DataParallelBPR:
         from .utils import _AdamView
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        # (the dense all-reduce, row-sharded and column-sharded modes refuse the optional branches: the first two were never wired to
+        #  carry the MLP gradients, the third cannot -- the gate's MLPs mix the columns of a row)
         if getattr(recmodel, 'has_variants', False) and not (getattr(recmodel, 'fused_variants', False) and reduce == 'rows' and shard == 'batch'):
             raise NotImplementedError("with the popularity gate / item-item smoothing, data-parallel training needs the fused step "
                                       "(--fused_variants 1) and the gradient-row exchange: reduce='rows', shard='batch'")
@@ -112,8 +151,8 @@ class DataParallelBPR:
         if reduce not in ('rows', 'dense'):
             raise ValueError("reduce must be 'rows' (all-gather of gradient rows) or 'dense' (all-reduce of the table)")
         self.reduce = reduce
-        if shard not in ('batch', 'rows'):
-            raise ValueError("shard must be 'batch' (replicated propagation) or 'rows' (row-sharded propagation)")
+        if shard not in ('batch', 'rows', 'cols'):
+            raise ValueError("shard must be 'batch' (replicated propagation), 'rows' (row-sharded propagation) or 'cols' (column-sharded tables)")
         self.shard = shard
         self.ranges = None
         if shard == 'rows':
@@ -216,6 +255,17 @@ class DataParallelBPR:
         m = self.model
         dev = m._table.device
         T = int(users.numel())
+        if self.shard == 'cols' and dev.type == 'cuda' and os.environ.get("LGCN_DP_PYTHON_LOOP") != "1" and self._own_communicator_ok():
+            users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)
+            st = m._state(max_batch=max(int(global_batch), int(m.config.get('bpr_batch_size', global_batch))), need_ctx=True, dp_world=1)
+            lib = _lib.load()
+            lib.lgcn_ctx_set_lr(st['ctx'], float(self.opt.param_groups[0]['lr']))
+            steps = (T + global_batch - 1) // global_batch
+            losses = torch.empty(steps, 3, dtype=torch.float32, device=dev)
+            _lib.check(lib.lgcn_train_epoch_dp(st['ctx'], self._communicator(), _lib.tp(users), _lib.tp(pos), _lib.tp(neg), T,
+                                               int(global_batch), 3, None, None, _lib.tp(losses), _lib.current_stream()), "lgcn_train_epoch_dp")
+            m._cache = None
+            return losses
         if dev.type != 'cuda' or os.environ.get("LGCN_DP_PYTHON_LOOP") == "1" or not self._own_communicator_ok():
             if self.shard == 'rows':        # (no per-step form exists: _step would come straight back here)
                 raise RuntimeError("row-sharded propagation (shard='rows') runs only through the library's RCCL communicator "
@@ -244,9 +294,39 @@ class DataParallelBPR:
         m._cache = None
         return losses
 
+    def gather_table(self):
+        """shard='cols': the full [N, d] table (every rank's columns, all-gathered) -- what evaluation scores with."""
+        t = self.model._table.detach().contiguous()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return torch.cat(parts, dim=1)
+
+    def _step_cols(self, users, pos, neg):
+        """one column-sharded step with the all-reduce through torch.distributed (the fallback of the C loop)"""
+        m = self.model
+        dev = m._table.device
+        users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)
+        B = int(users.numel())
+        st = m._state(max_batch=max(B, int(m.config.get('bpr_batch_size', B))), need_ctx=True, dp_world=1)
+        lib = _lib.load()
+        lib.lgcn_ctx_set_lr(st['ctx'], float(self.opt.param_groups[0]['lr']))
+        stream = _lib.current_stream()
+        ptr = C.c_void_p()
+        _lib.check(lib.lgcn_train_step_cols_part1(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B, C.byref(ptr), stream),
+                   "lgcn_train_step_cols_part1")
+        partial = torch.as_tensor(_DevArray(ptr.value, 3 * B), device=dev)
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group)
+        loss = torch.empty(3, dtype=torch.float32, device=dev)
+        _lib.check(lib.lgcn_train_step_cols_part2(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B, _lib.tp(loss), stream),
+                   "lgcn_train_step_cols_part2")
+        m._cache = None
+        return loss
+
     def _step(self, users, pos, neg):
         if self.shard == 'rows':
             return self.train_epoch(users, pos, neg, int(len(users)))[0]
+        if self.shard == 'cols':
+            return self._step_cols(users, pos, neg)
         m = self.model
         dev = m._table.device
         users, pos, neg = m._ids(users, dev), m._ids(pos, dev), m._ids(neg, dev)

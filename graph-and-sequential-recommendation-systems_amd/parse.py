@@ -58,8 +58,9 @@ def build_parser():
     p.add_argument('--sampler', type=str, default='auto', choices=['auto', 'cpp', 'python'],
                    help="NEW: 'cpp' = sampling.cpp stream, 'python' = numpy fallback stream, "
                         "'auto' = cpp unless a user has no positives")
-    p.add_argument('--act_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
-                   help='NEW: storage type of propagated layer activations (accumulation is fp32)')
+    p.add_argument('--act_dtype', type=str, default='fp32', choices=['fp32', 'bf16', 'fp8'],
+                   help='NEW: storage type of propagated layer activations, forward and backward (accumulation, parameters and Adam '
+                        'state stay fp32). fp8 = OCP E4M3 with a power-of-two fp32 scale per row; d >= 64, default model only')
     p.add_argument('--xcd_remap', type=int, default=1,
                    help='NEW: give every XCD a contiguous range of graph rows')
     p.add_argument('--row_order', type=str, default='xcd', choices=['natural', 'rcm', 'cocluster', 'xcd'],

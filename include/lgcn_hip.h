@@ -28,7 +28,13 @@ extern "C" {
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
-enum { LGCN_F32 = 0, LGCN_BF16 = 1 };
+enum { LGCN_F32 = 0, LGCN_BF16 = 1, LGCN_FP8 = 2 };
+/* LGCN_FP8: a table of n rows is n*d bytes of OCP E4M3 values FOLLOWED BY n fp32 row scales (value = scale * fp8), one pointer
+ * for both; scales are powers of two with max|row| / scale in [64, 128).  d must be 64, 128 or 256.  Accumulation is fp32 as
+ * with every storage type.  lgcn_table_bytes: bytes of one [n_rows, d] table of a storage type (fp8: rows + scales, padded
+ * to 256); lgcn_to_fp8: quantise an fp32 table (device pointers).                                                     */
+int64_t lgcn_table_bytes(int64_t n_rows, int32_t d, int32_t dtype);
+int lgcn_to_fp8(const float *src, void *dst, int64_t n_rows, int32_t d, void *stream);
 
 int lgcn_abi_version(void);
 const char *lgcn_last_error(void);
@@ -155,14 +161,14 @@ typedef struct {
     int32_t n_users;
     int32_t d;                  /* latent_dim_rec: 32/64/128/256 */
     int32_t K;                  /* lightGCN_n_layers: 1..LGCN_MAX_LAYERS */
-    int32_t act_dtype;          /* LGCN_F32 | LGCN_BF16: storage of layer activations */
+    int32_t act_dtype;          /* LGCN_F32 | LGCN_BF16 | LGCN_FP8: storage of layer activations (forward X_k and backward h_k) */
     /* parameters + Adam state, fp32 [N,d]: rows [0,n_users) = embedding_user.weight,
      * rows [n_users,N) = embedding_item.weight (model.py:57-60) */
     float *E0;
     float *adam_m;
     float *adam_v;
     /* workspace, caller-allocated, zero-initialised before the first step */
-    void *act;                  /* max(1, dense_last ? K : K-1) * N*d elements of act_dtype */
+    void *act;                  /* max(1, dense_last ? K : K-1) tables of lgcn_table_bytes(N, d, act_dtype) bytes each */
     int64_t *G64;               /* [N,d] fixed-point (2^50) accumulator of the sparse-row gradient */
     uint32_t *bitmap;           /* [2*ceil(N/32)] rows of G64 that are non-zero (two, used alternately) */
     float *terms;               /* [2*max_batch] per-triplet loss / reg terms */
@@ -270,6 +276,18 @@ int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t 
                              const int32_t *neg, int32_t B_global, int32_t world,
                              const float *gathered, float *loss_out, void *stream);
 
+/* Column-sharded data parallelism (LGCN_DP_COLS): rank r holds columns [r*d/W, (r+1)*d/W) of the tables -- its context is an
+ * ordinary context of width d/W (32/64/128/256) over the same graph, cfg.contrib holding 3*max_batch*(d/W) floats.  Every rank
+ * sees the WHOLE batch.  part 1: forward + the batch's slot rows + the PARTIAL scores / reg terms over this rank's columns
+ * (*partials = device float[3*B]: pos score | neg score | reg term); the caller all-reduces (SUM) those 3*B floats over the
+ * ranks IN PLACE; part 2: loss terms, gradient rows of this rank's columns, backward, Adam.  One 3*B-float collective per
+ * step and per-rank SpMM work that falls with W.  Equal to lgcn_train_step up to the summation order of the dot products
+ * (W partial sums).  lgcn_train_epoch_dp(reduce = LGCN_DP_COLS) runs the loop with the all-reduce on the communicator.     */
+int lgcn_train_step_cols_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                               int32_t B, float **partials, void *stream);
+int lgcn_train_step_cols_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,
+                               int32_t B, float *loss_out, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Device: fused full-ranking evaluation -- replaces the body of Procedure.Test  */
 /* ------------------------------------------------------------------------ */
@@ -322,7 +340,7 @@ int lgcn_eval_metrics(const int32_t *topk_items, int32_t n_eval, int32_t K,
  * per process / GPU.  Rank 0 creates the 128-byte id (ncclGetUniqueId) and the caller hands it to
  * every rank through any channel it has (torch.distributed store, MPI, a file).             */
 #define LGCN_DP_ID_BYTES 128
-enum { LGCN_DP_ROWS = 0, LGCN_DP_DENSE = 1, LGCN_DP_ROW_SHARDED = 2 };
+enum { LGCN_DP_ROWS = 0, LGCN_DP_DENSE = 1, LGCN_DP_ROW_SHARDED = 2, LGCN_DP_COLS = 3 };
 typedef struct lgcn_dp lgcn_dp;   /* opaque */
 int lgcn_dp_available(void);                         /* 1 if RCCL could be resolved */
 int lgcn_dp_unique_id(void *id128);

@@ -214,3 +214,59 @@ def test_communicator_failure_falls_back_on_every_rank(tmp_path, case):
     out = os.path.join(str(tmp_path), "ok.txt")
     mp.spawn(_comm_fail_worker, args=(2, _free_port(), out, case), nprocs=2, join=True)
     assert open(out).read() == "1"
+
+
+def _cols_worker(rank, world, port, out):
+    """Column-sharded step (parallel.py shard='cols') over gloo, on the oracle's numbers: every rank propagates ITS columns of the
+    table (propagation is per column), forms the partial scores / reg terms of the whole batch over those columns, all-reduces
+    the 3*B floats, and builds the gradient rows of its columns from the COMPLETE scores -- the concatenation over the ranks
+    must be the oracle's single-process G and loss."""
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG_NAME)
+    from oracle import oracle as orc
+    g = GoldenSet("tiny")
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    lo, hi = pkg.parallel.column_range(g.d, world, rank)
+    E_loc = orc.propagate(*A, np.ascontiguousarray(g.e0()[:, lo:hi]), g.K)              # this rank's columns only
+    E = orc.propagate(*A, g.e0(), g.K)
+    rng = np.random.Generator(np.random.PCG64(3))
+    B = 41
+    users = rng.integers(0, g.n_users, B); pos = rng.integers(0, g.m_items, B); neg = rng.integers(0, g.m_items, B)
+    users[:3] = users[0]; pos[5] = neg[6]
+    eu, ep, en = E_loc[users], E_loc[g.n_users + pos], E_loc[g.n_users + neg]
+    part = np.concatenate([(eu * ep).sum(1), (eu * en).sum(1), (eu * eu + ep * ep + en * en).sum(1)]).astype(np.float32)
+    t = torch.from_numpy(part.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ps, ns, rr = t.numpy()[:B], t.numpy()[B:2 * B], t.numpy()[2 * B:]
+    x = ps - ns
+    z = np.exp(-np.abs(x)); sig_neg = np.where(x < 0, 1 / (1 + z), z / (1 + z))
+    gb = (-(1.0 / B) * sig_neg).astype(np.float32)[:, None]; lam = np.float32(g.meta["decay"] / B)
+    G_loc = np.zeros_like(E_loc, dtype=np.float64)
+    np.add.at(G_loc, users, gb * (ep - en) + lam * eu)
+    np.add.at(G_loc, g.n_users + pos, gb * eu + lam * ep)
+    np.add.at(G_loc, g.n_users + neg, -gb * eu + lam * en)
+    bpr, reg, G_ref = orc.bpr(E, g.n_users, users, pos, neg, g.meta["decay"])
+    loss = -(np.minimum(x, 0) - np.log1p(z)).sum() / B
+    ok = (np.allclose(E_loc, E[:, lo:hi], rtol=0, atol=0)                                # propagation IS per column (bit for bit)
+          and np.allclose(G_loc, G_ref[:, lo:hi], rtol=2e-5, atol=1e-9) and abs(loss - bpr) < 1e-6 and abs(0.5 * rr.sum() / B - reg) < 1e-6)
+    tt = torch.tensor([1 if ok else 0]); dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(out, "w").write(str(int(tt.item())))
+    dist.destroy_process_group()
+
+
+def test_column_sharded_step_two_gloo_ranks(tmp_path):
+    out = os.path.join(str(tmp_path), "ok_cols.txt")
+    mp.spawn(_cols_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "1"
+
+
+def test_column_range(pkg):
+    par = pkg.parallel
+    assert [par.column_range(64, 2, r) for r in range(2)] == [(0, 32), (32, 64)]
+    assert [par.column_range(256, 8, r) for r in (0, 7)] == [(0, 32), (224, 256)]
+    for d, w in ((64, 4), (64, 3), (128, 8)):
+        with pytest.raises(ValueError):
+            par.column_range(d, w, 0)
