@@ -88,7 +88,7 @@ def test_spmm_edge_cases(pkg, oracle):
                 torch.zeros(1, device=DEV))                                               # non-monotone indptr
 
 
-def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="cocluster", reg_rows="propagated", d=None):
+def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="cocluster", reg_rows="propagated", dim=None):
     d = os.path.join(str(tmp_path), g.name + act_dtype)
     os.makedirs(d, exist_ok=True)
     for f in ("train.txt", "test.txt"):
@@ -96,7 +96,7 @@ def _make_model(pkg, g, tmp_path, act_dtype="fp32", K=None, B=None, row_order="c
     w = pkg.world
     w.configure([])
     w.dataset = g.name
-    w.config.update({'lightGCN_n_layers': K or g.K, 'latent_dim_rec': d or g.d, 'bpr_batch_size': B or g.B,
+    w.config.update({'lightGCN_n_layers': K or g.K, 'latent_dim_rec': dim or g.d, 'bpr_batch_size': B or g.B,
                      'act_dtype': act_dtype, 'decay': g.meta["decay"], 'lr': g.meta["lr"], 'row_order': row_order,
                      'reg_rows': reg_rows})
     w.config['checkpoint_dir'] = os.path.join(str(tmp_path), "ckpt")
@@ -502,7 +502,7 @@ def test_dp_cols_epoch_loopback(pkg, tiny, tmp_path, world, d, act, reg_rows):
     u = rng.integers(0, g.n_users, T); p = rng.integers(0, g.m_items, T); n = rng.integers(0, g.m_items, T)
     u[5] = u[40]; p[7] = p[30]; n[9] = p[30]
     U, P, Nn = (_dev(x, torch.int32) for x in (u, p, n))
-    ds, ref = _make_model(pkg, g, tmp_path, act_dtype=act, B=B, reg_rows=reg_rows, d=d)
+    ds, ref = _make_model(pkg, g, tmp_path, act_dtype=act, B=B, reg_rows=reg_rows, dim=d)
     E0_full = ref._table.detach().clone()
     want_loss = ref.fused_epoch(U, P, Nn, B).cpu().numpy()
     want = ref._table.detach().cpu().numpy()
