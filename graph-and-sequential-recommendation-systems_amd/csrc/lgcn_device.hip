@@ -1045,6 +1045,10 @@ __device__ __forceinline__ void triplet_finish(const BprArgs &a, int b, int l, c
 #ifndef TRIPLET_U
 #define TRIPLET_U LGCN_GATHER_U   /* gathers in flight per lane in k_triplet */
 #endif
+#ifndef TRIPLET_WAVES
+#define TRIPLET_WAVES 4        /* waves per k_triplet workgroup: 4 = three gathering waves + one that reads the lower layers' rows; 3 = every wave
+                                  reads the lower-layer rows of its own slot before it gathers (more workgroups resident per CU) */
+#endif
 #ifndef ROWS_UNIT_TILES
 #define ROWS_UNIT_TILES 2      /* 64-entry tiles per unit of a slot row */
 #endif
@@ -1066,7 +1070,7 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
         const int cnt = tile_stage<false>(cv.x, __int_as_float(cv.y), min(64, n - t * 64), src, lane, stage);
         __builtin_amdgcn_wave_barrier();
         int tn = t + 1;
-        if (tn % UT == 0) tn += 3 * UT;
+        if (tn % UT == 0) tn += (TRIPLET_WAVES - 1) * UT;
         const bool more = tn < ntiles;
         cv = make_int2(0, 0);
         if (more && tn * 64 + lane < n) cv = es.at(start + tn * 64 + lane);
@@ -1080,7 +1084,8 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
 
 // TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
 template <int D, typename TG, typename TI, bool BIG>
-__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[4][D], float (*base)[D], float (*ego)[D]) {
+__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[TRIPLET_WAVES][D], float (*base)[D], float (*ego)[D]) {
+    constexpr int NW = TRIPLET_WAVES;
     typedef Geo<D, TG, false> G;
     constexpr int C = G::CPL, LPR = G::LPR, UN = 64 * ROWS_UNIT_TILES;
     constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT;      // lane = column (mod 64) layout of the finishing steps
@@ -1093,35 +1098,37 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
     const int64_t row0 = bad ? 0 : (int64_t)a.users[b], row1 = bad ? 0 : (int64_t)a.pos[b] + a.n_users, row2 = bad ? 0 : (int64_t)a.neg[b] + a.n_users;
     const int st0 = a.indptr[row0], st1 = a.indptr[row1], st2 = a.indptr[row2];
     const int n0 = a.indptr[row0 + 1] - st0, n1 = a.indptr[row1 + 1] - st1, n2 = a.indptr[row2 + 1] - st2;
-    if (w == 3 && lane < LPT) {
-        // the spare wave: the K lower layers' rows of the three slots, summed in layer order, while waves 0-2 gather
+    // the K lower layers' rows of a slot, summed in layer order (lane = column)
+    auto base_row = [&](int c) {
+        const int64_t row = c == 0 ? row0 : (c == 1 ? row1 : row2);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int64_t row = c == 0 ? row0 : (c == 1 ? row1 : row2);
-#pragma unroll
-            for (int j = 0; j < CPT; j++) {
-                const int col = j * LPT + lane;
-                float s = a.X0[row * D + col];
-                if (a.reg_ego) ego[c][col] = s;
-                for (int k = 1; k < a.K; k++) s += tab_elem<TI>(a.Xl[k], a.N, D, row, col);
-                base[c][col] = s;
-            }
+        for (int j = 0; j < CPT; j++) {
+            const int col = j * LPT + lane;
+            float s = a.X0[row * D + col];
+            if (a.reg_ego) ego[c][col] = s;
+            for (int k = 1; k < a.K; k++) s += tab_elem<TI>(a.Xl[k], a.N, D, row, col);
+            base[c][col] = s;
         }
+    };
+    if (NW == 4 && w == 3 && lane < LPT) {              // the spare wave does all three while waves 0-2 gather
+#pragma unroll
+        for (int c = 0; c < 3; c++) base_row(c);
     }
     GatherSrc src; src.bm = nullptr; src.div = 1.f; src.X = Xg;
     src.S = sizeof(TG) == 1 ? fp8_scales(Xg, a.N, D) : nullptr;
     tile_pad_init(stage, threadIdx.x & 63);
-    bool any = (w == 0 || w == 3);
+    bool any = NW == 3 || (w == 0 || w == 3);
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {                       // (not unrolled: three inlined copies of the gather loop cost 20 VGPRs)
         const int stc = c == 0 ? st0 : (c == 1 ? st1 : st2), nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
-        const int u0 = (w - c + 4) & 3, units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
+        const int u0 = NW == 4 ? ((w - c + 4) & 3) : ((w - c + 3) % 3), units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
         if (u0 < units) {
             const typename G::Acc x = units_gather<D, TG, BIG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
             if (lane < LPR) storev<C>(&part[c][w][lane * C], x);
             any = true;
         }
     }
+    if (NW == 3 && lane < LPT) base_row(w);             // three-wave form: wave w owns slot w's lower-layer rows (behind its gathers)
     if (!any) return;                  // s_barrier counts only the surviving waves
     __syncthreads();
     if (w != 0 || lane >= LPT) return;
@@ -1139,7 +1146,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
             const int col = j * LPT + lane;
             float xk = hub ? a.Xhub[rowc * D + col] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; i++) if (i < units) xk += part[c][(c + i) & 3][col];     // unit 0's wave first
+            for (int i = 0; i < NW; i++) if (i < units) xk += part[c][(c + i) % NW][col];     // unit 0's wave first
             e[c][j] = (base[c][col] + xk) / div;
         }
     }
@@ -1154,13 +1161,13 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
 }
 
 template <int D, typename TI, bool BIG>
-__global__ void __launch_bounds__(256, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
-    __shared__ int2 stage_lds[4][TILE_ST];
-    __shared__ __attribute__((aligned(32))) float part_lds[3][4][D];
+__global__ void __launch_bounds__(64 * TRIPLET_WAVES, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
+    __shared__ int2 stage_lds[TRIPLET_WAVES][TILE_ST];
+    __shared__ __attribute__((aligned(32))) float part_lds[3][TRIPLET_WAVES][D];
     __shared__ float base_lds[3][D];
     __shared__ float ego_lds[3][D];          // reg_ego: the slots' rows of the table itself
     // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * 256)
+    for (int64_t i = (int64_t)blockIdx.x * (64 * TRIPLET_WAVES) + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * (64 * TRIPLET_WAVES))
         a.stale_bitmap[i] = 0u;
     int2 *stage = stage_lds[threadIdx.x >> 6];
     if (a.K == 1) triplet_body<D, float, TI, BIG>(a, a.X0, stage, part_lds, base_lds, ego_lds);
@@ -2243,8 +2250,8 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
                 if (c.dense_last) {
                     const int tpb = 256 / 64;
                     hipLaunchKernelGGL((k_triplet_dense<D, fp8_t>), dim3((unsigned)((B_local + tpb - 1) / tpb)), dim3(256), 0, st, a);
-                } else if (big_table(x->N, D)) hipLaunchKernelGGL((k_triplet<D, fp8_t, true>), dim3(B_local), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((k_triplet<D, fp8_t, false>), dim3(B_local), dim3(256), 0, st, a);
+                } else if (big_table(x->N, D)) hipLaunchKernelGGL((k_triplet<D, fp8_t, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+                else hipLaunchKernelGGL((k_triplet<D, fp8_t, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
             }
         } else if (c.dense_last) {
             const int tpb = 256 / (D < 64 ? D : 64);
@@ -2252,10 +2259,10 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
             if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_triplet_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
         } else if (big_table(x->N, D)) {
-            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, true>), dim3(B_local), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_triplet<D, bf16_t, true>), dim3(B_local), dim3(256), 0, st, a);
-        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, false>), dim3(B_local), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_triplet<D, bf16_t, false>), dim3(B_local), dim3(256), 0, st, a);
+            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+            else hipLaunchKernelGGL((k_triplet<D, bf16_t, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+        else hipLaunchKernelGGL((k_triplet<D, bf16_t, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
     });
     return 0;
 }

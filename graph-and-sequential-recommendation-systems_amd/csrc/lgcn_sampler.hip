@@ -402,7 +402,9 @@ extern "C" int lgcn_sample_negative_device(int user_num, int item_num, int64_t t
     g.pairs = (uint2 *)(seg_ws + 256);
     g.pair_cnt = (int *)(g.pairs + seg_pair_blocks() * SAMP_PCAP);
     g.events = (SampEvent *)(((uintptr_t)(g.pair_cnt + seg_pair_blocks()) + 15) & ~(uintptr_t)15);
-    const bool segments = SAMP_SEGMENTS != 0;
+    // k_samp_pairs tests every position against the SAMP_DMAX / 2 / per_user + 1 users whose triplets can read it: with very few
+    // interactions per user that is dozens of binary searches per position -- the one-workgroup kernel does those datasets
+    const bool segments = SAMP_SEGMENTS != 0 && per_user >= 8;
     if (hipMemsetAsync(g.st, 0, sizeof(SampState), st) != hipSuccess) { lgcn_set_error("sample_negative_device: memset failed"); return 10; }
     if (segments) {
         // a segment should end by itself, not on SAMP_DMAX: size it for half that many expected rejections (rate = deg / items)

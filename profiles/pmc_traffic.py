@@ -33,7 +33,7 @@ def main():
     write = sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--write" else None
     out_path = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--out" else os.path.join(REPO, "profiles", "hbm_traffic.json")
     out = {}
-    for dt in ("fp32", "bf16"):
+    for dt in ("fp32", "bf16", "fp8"):
         vals = {}
         for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
             for k, cs in counters(os.path.join(root, f"{sub}_{dt}")).items():
