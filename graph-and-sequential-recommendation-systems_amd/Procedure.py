@@ -205,7 +205,7 @@ def _test_fused(Recmodel, ev, max_K):
     n = len(ev.users)
     dev = E.device
     topk = torch.empty(n, max_K, dtype=torch.int32, device=dev)
-    _lib.check(lib.lgcn_eval_topk_masked(_lib.tp(E), Recmodel.n_users, Recmodel.m_items, Recmodel.latent_dim,
+    _lib.check(lib.lgcn_eval_topk_masked(_lib.tp(E), Recmodel.n_users, Recmodel.m_items, int(E.shape[1]),      # (a column shard scores with the gathered table)
                                          _lib.tp(ev.users32), n, _lib.tp(ev.train_ptr), _lib.tp(ev.train_idx32),
                                          max_K, _lib.tp(topk), None, _lib.tp(ev.masks) if ev.masks is not None else None,
                                          _lib.current_stream()), "lgcn_eval_topk")

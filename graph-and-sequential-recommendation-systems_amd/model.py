@@ -441,6 +441,16 @@ class LightGCN(nn.Module):
         if self._cache is None:
             with torch.no_grad():
                 out = self._propagate_dense()
+                cr = getattr(self, 'col_range', None)
+                if cr is not None and cr[1] - cr[0] < cr[2]:
+                    # a column shard of a wider model (parallel.column_shard): propagation is per column, so the ranks' propagated
+                    # columns side by side ARE the full propagated table -- what evaluation has to score with
+                    import torch.distributed as dist
+                    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() * (cr[1] - cr[0]) == cr[2]):
+                        raise _lib.LgcnError("this model holds columns %d..%d of %d: evaluation needs the process group that holds the others" % cr)
+                    parts = [torch.empty_like(out) for _ in range(dist.get_world_size())]
+                    dist.all_gather(parts, out.contiguous())
+                    out = torch.cat(parts, dim=1)
                 if self.i2i_active:
                     out = torch.cat([out[:self.n_users], self._i2i_apply(out[self.n_users:], transpose=False)], dim=0)
                 self._cache = out

@@ -9,7 +9,7 @@ timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo
 tail -4 $OUT/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.txt
 cd /tmp && export TMPDIR=/tmp
-for wl in gowalla yelp2018-shaped amazon-book-shaped synthetic-10m; do
+for wl in gowalla yelp2018-shaped amazon-book-shaped; do        # (synthetic-10m: run12.sh)
   mkdir -p $OUT/pmc_$wl
   for dt in fp32 bf16 fp8; do
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$wl/pmc_fetch_$dt -- python3 $ROOT/bench.py --workload $wl --spmm_only --spmm_reps 20 --act_dtype $dt > $OUT/pmc_$wl/f_$dt.log 2>&1
