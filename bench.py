@@ -512,9 +512,10 @@ def main():
                                     "abs_diff_ndcg": abs(res["ndcg"] - gold["ndcg"][0]),
                                     "within_1e-4": bool(abs(res["recall"] - gold["recall"][0]) <= 1e-4 and abs(res["ndcg"] - gold["ndcg"][0]) <= 1e-4)}
             e2e.update({"steps_per_epoch": steps_per_epoch, "epochs_timed": 9,
-                        "what": "Procedure.BPR_train_original: device sampler (bit-exact sampling.cpp stream) + host numpy shuffle + "
-                                "permutation apply + the fused steps; prefetch_on samples epoch e+1 on a side stream under epoch e "
-                                "(same triplets), prefetch_off is the reference's strict order"})
+                        "what": "Procedure.BPR_train_original: device sampler (bit-exact sampling.cpp stream) + the numpy-legacy shuffle "
+                                "(MT19937 + Fisher-Yates, same permutation; on the device since round 4) + permutation apply + the fused "
+                                "steps; prefetch_on samples epoch e+1 on a side stream under epoch e (same triplets), prefetch_off is the "
+                                "reference's strict order"})
             out["end_to_end_epoch"] = e2e
             out["quality"] = {"epochs": 10, "seed": 2020,
                               "reference": {"recall@20": gold["recall"][0], "ndcg@20": gold["ndcg"][0], "precision@20": gold["precision"][0],

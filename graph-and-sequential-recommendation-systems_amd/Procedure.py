@@ -42,13 +42,16 @@ def sample_epoch_to_device(dataset, device):
             world.cprint("[sampler] GPU sampler margin exceeded (dense dataset): host sampler for this epoch")
     if S32 is not None:
         T = int(S32.shape[0])
-        perm = utils.shuffle_indices(T)
     else:
         S = utils.UniformSample_original(dataset)
         T = len(S)
-        perm = utils.shuffle_indices(T)
         S32 = torch.from_numpy(np.ascontiguousarray(S[:, :3], dtype=np.int32)).to(device)
-    permd = torch.from_numpy(perm).to(device)
+    permd = None
+    if torch.device(device).type == 'cuda' and int(world.config.get('gpu_shuffle', 1)) and 2 <= T < (1 << 31) - 16:
+        # utils.shuffle's permutation (np.random.shuffle of arange: utils.py:148-149) from the same MT19937 stream, on the device
+        permd = utils.shuffle_indices_device(T, device)
+    if permd is None:
+        permd = torch.from_numpy(utils.shuffle_indices(T)).to(device)
     users = torch.empty(T, dtype=torch.int32, device=device)
     pos = torch.empty_like(users)
     neg = torch.empty_like(users)

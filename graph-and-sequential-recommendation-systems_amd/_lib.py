@@ -43,6 +43,8 @@ SIGNATURES = {
     "lgcn_abi_version": (C.c_int, []),
     "lgcn_last_error": (C.c_char_p, []),
     "lgcn_device_available": (C.c_int, []),
+    "lgcn_np_shuffle_perm_device_workspace": (C.c_int64, [C.c_int64]),
+    "lgcn_np_shuffle_perm_device": (C.c_int, [C.c_int64, _vp, _vp, C.c_int64, _vp]),
     "lgcn_table_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "lgcn_to_fp8": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp]),
     "lgcn_sampling_seed": (None, [C.c_uint]),

@@ -123,6 +123,10 @@ public:
         return v;
     }
 
+    // the whole state, for the device form of the shuffle (lgcn_shuffle.hip): key[624] + read position
+    void get_state(uint32_t *key, uint32_t *pos) const { std::memcpy(key, mt_, sizeof mt_); *pos = idx_; }
+    void set_state(const uint32_t *key, uint32_t pos) { std::memcpy(mt_, key, sizeof mt_); idx_ = pos > kN ? kN : pos; }
+
 private:
     static constexpr uint32_t kN = 624, kM = 397;
     void refill() {
@@ -253,6 +257,8 @@ void lgcn_glibc_block_histories(int64_t nblocks, int64_t block_len, uint32_t *ou
 void lgcn_glibc_advance(uint64_t n) { g_rand.jump(n); }
 
 void lgcn_np_seed(uint32_t seed) { g_np.seed(seed); }
+void lgcn_np_get_state(uint32_t *key624, uint32_t *pos) { g_np.get_state(key624, pos); }
+void lgcn_np_set_state(const uint32_t *key624, uint32_t pos) { g_np.set_state(key624, pos); }
 
 int64_t lgcn_sample_python(int n_users, int m_items, int64_t train_num, const int64_t *indptr,
                            const int32_t *indices, int64_t *S_out) {

@@ -80,6 +80,9 @@ def build_parser():
                         'step instead of from every triplet that names them (0 = library default 131072, < 0 = off)')
     p.add_argument('--gpu_sampler', type=int, default=1,
                    help='NEW: 1 = the cpp-mode BPR sampler runs on the GPU (same rand() stream, same rows); 0 = on the host')
+    p.add_argument('--gpu_shuffle', type=int, default=1,
+                   help='NEW: 1 = the epoch permutation (numpy legacy shuffle: MT19937 + Fisher-Yates, same stream, same permutation) is '
+                        'computed on the GPU; 0 = on the host')
     p.add_argument('--eval_fused', type=int, default=1,
                    help='NEW: 1 = Procedure.Test through the fused HIP kernels (MFMA scores + mask + top-k, metrics on device); '
                         '0 = torch matmul/topk harness')

@@ -212,6 +212,23 @@ def shuffle_indices(n):
     return perm
 
 
+_SHUFFLE_WS = {}      # (device, n) -> workspace tensor of the device shuffle
+
+
+def shuffle_indices_device(n, device):
+    """The same permutation from the same stream, produced on the GPU (csrc/lgcn_shuffle.hip) -> device int64 [n]."""
+    lib = _lib.load()
+    key = (str(device), int(n))
+    ws = _SHUFFLE_WS.get(key)
+    if ws is None:
+        _SHUFFLE_WS.clear()
+        ws = _SHUFFLE_WS[key] = torch.empty(int(lib.lgcn_np_shuffle_perm_device_workspace(int(n))), dtype=torch.uint8, device=device)
+    perm = torch.empty(int(n), dtype=torch.int64, device=device)
+    _lib.check(lib.lgcn_np_shuffle_perm_device(int(n), _lib.tp(perm), _lib.tp(ws), int(ws.numel()), _lib.current_stream()),
+               "lgcn_np_shuffle_perm_device")
+    return perm
+
+
 def shuffle(*arrays, **kwargs):
     """utils.py:142-151."""
     require_indices = kwargs.get('indices', False)

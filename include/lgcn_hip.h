@@ -144,6 +144,13 @@ int lgcn_spmm_csr(const lgcn_graph *g, const void *X, int x_dtype, void *Y, int 
 int lgcn_propagate_mean(const lgcn_graph *g, const float *E0, int K, int d, int act_dtype,
                         void *work, float *out, void *stream);
 
+/* The same permutation from the same stream, produced ON THE DEVICE (d_perm: device int64[n]): one wave twists MT19937 in LDS
+ * and aligns the draws to the Fisher-Yates steps as it generates them (64 per pass), then the swaps are resolved as sorted chains +
+ * pointer doubling (csrc/lgcn_shuffle.hip).  The host generator is set to where the device stopped, so host and device calls mix
+ * freely.  workspace: device bytes from lgcn_np_shuffle_perm_device_workspace(n).  Returns 3 for n >= 2^31 - 16 (the caller then
+ * uses lgcn_np_shuffle_perm).  Synchronises `stream`. */
+int64_t lgcn_np_shuffle_perm_device_workspace(int64_t n);
+int lgcn_np_shuffle_perm_device(int64_t n, int64_t *d_perm, void *workspace, int64_t workspace_bytes, void *stream);
 /* users/pos/neg[T] = S[perm[t], 0..2] -- the device side of utils.shuffle
  * (utils.py:150) applied to the sampler output (main.py:217-220).            */
 int lgcn_apply_perm(const int32_t *S, int s_cols, const int64_t *perm, int64_t T,

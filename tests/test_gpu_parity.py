@@ -1503,6 +1503,54 @@ def test_gpu_sampler_segments_heavy_tail_bit_exact(pkg):
     assert tail_host == tail_dev
 
 
+def test_device_shuffle_bit_exact(pkg):
+    """lgcn_np_shuffle_perm_device: np.random.shuffle(arange(n)) (utils.py:148-149, numpy's legacy MT19937 + masked-rejection
+    Fisher-Yates) computed on the GPU -- MT19937 twisted in LDS, the draw-to-step alignment 256 draws at a time, the swaps as
+    sorted chains + pointer doubling -- against the host restatement lgcn_np_shuffle_perm (which test_oracle / test_host pin to
+    numpy itself): identical permutations for sizes around every special case (one and two steps, the serial tail at 1024, chunk
+    and mask boundaries, powers of two +- 1, Gowalla's epoch), starting in the middle of a generator block, and the generator
+    left exactly where the host loop leaves it (host and device calls interleaved draw the same stream)."""
+    U = pkg.utils
+    sizes = [1, 2, 3, 7, 64, 255, 256, 257, 1000, 1023, 1024, 1025, 1279, 1280, 1281, 1535, 1536, 2047, 2048, 2049, 4095, 4097, 5000,
+             65535, 65536, 65537, 65536 + 255, 65536 + 256, 65536 + 257, 70000, 131071, 131072 + 300, 806166, 810128,
+             (1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 255, (1 << 20) + 256, (1 << 20) + 700]
+    for seed in (2020, 7):
+        U.set_seed(seed)
+        want = [U.shuffle_indices(n) for n in sizes]
+        tail_host = U.shuffle_indices(50)
+        U.set_seed(seed)
+        for n, w_ in zip(sizes, want):
+            got = U.shuffle_indices_device(n, DEV).cpu().numpy()
+            assert got.dtype == np.int64 and np.array_equal(got, w_), (seed, n, np.flatnonzero(got != w_)[:5])
+        assert np.array_equal(U.shuffle_indices(50), tail_host), seed          # same stream position afterwards
+    # interleaved: host, device, host, device ... on one stream
+    U.set_seed(99)
+    want = [U.shuffle_indices(n) for n in (5000, 300, 70001, 9, 2500)]
+    U.set_seed(99)
+    got = [U.shuffle_indices(5000), U.shuffle_indices_device(300, DEV).cpu().numpy(), U.shuffle_indices(70001),
+           U.shuffle_indices_device(9, DEV).cpu().numpy(), U.shuffle_indices_device(2500, DEV).cpu().numpy()]
+    for a_, b_ in zip(want, got):
+        assert np.array_equal(a_, b_)
+    # and it is a permutation numpy itself produces
+    rs = np.random.RandomState(5); ref = np.arange(4097); rs.shuffle(ref)
+    U.set_seed(5)
+    assert np.array_equal(U.shuffle_indices_device(4097, DEV).cpu().numpy(), ref)
+
+
+def test_epoch_triplets_device_shuffle_equals_host_shuffle(pkg, tiny, tmp_path):
+    """Procedure.sample_epoch_to_device with --gpu_shuffle 1 (default) and 0: the same shuffled triplets, three epochs in a row."""
+    out = []
+    for flag in (1, 0):
+        ds, m = _make_model(pkg, tiny, tmp_path)
+        pkg.world.config['gpu_shuffle'] = flag
+        pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+        out.append([tuple(t.cpu().numpy() for t in pkg.Procedure.sample_epoch_to_device(ds, DEV)) for _ in range(3)])
+    pkg.world.config['gpu_shuffle'] = 1
+    for e in range(3):
+        for c in range(3):
+            assert np.array_equal(out[0][e][c], out[1][e][c]), (e, c)
+
+
 def test_gpu_sampler_segments_reach_the_end_of_the_stream(pkg):
     """a MID-density dataset (2.5 % of the items positive per user: the segments complete, none overflows a
     capacity) whose rejections need more draws than the stream margin holds.  The segment kernels skip positions past the
