@@ -280,6 +280,21 @@ def main():
                 "gather": {"bound": "l2-gather", "achieved": nnz * d * s / t_spmm / 1e9, "peak": 17800.0, "unit": "GB/s",
                            "frac": nnz * d * s / t_spmm / 1e9 / 17800.0}}
 
+    def stream_copy_gbs():
+        """the box's measured stream-copy bandwidth (report it beside the 8 TB/s spec): a device-to-device copy of 1 GiB,
+        bytes read + bytes written per second"""
+        n = 1 << 28
+        src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        return 2.0 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     if a.spmm_only:
         reps = a.spmm_reps if a.workload != "synthetic-10m" else min(a.spmm_reps, 5)
         print(json.dumps({"spmm_only": True, "workload": a.workload, "act_dtype": a.act_dtype,
@@ -416,6 +431,13 @@ def main():
             # the dominant kernel of that other mode (BASELINE configs[1] names bf16 activation storage), same definition
             out[f"roofline_{secondary[0]}"] = roofline(secondary[2], ACT[secondary[0]][0])
         out["roofline"] = roofline(t_spmm)
+        try:
+            sc = stream_copy_gbs()
+            out["roofline"]["stream_copy_measured"] = {"GB/s": sc, "what": "device-to-device copy of 1 GiB, read + write bytes per second (torch copy kernel)",
+                                                       "frac_of_measured": out["roofline"]["achieved"] / sc}
+            out["step_roofline_frac_of_measured_stream"] = out["step_algorithmic_bytes"] * out["value"] / (sc * 1e9)
+        except Exception as e:      # noqa: BLE001
+            out["roofline"]["stream_copy_measured"] = {"error": repr(e)}
 
     # ---- the evaluation kernel on the same model (reported, not the headline): Procedure.Test's scoring +
     #      masking + top-20 in one launch, priced against the fp32 matrix-core peak (the reference ranks in fp32)
