@@ -222,6 +222,33 @@ def test_config_surface_matches_reference_flags(pkg):
     w.configure([])
 
 
+def test_additive_flags_default_to_the_reference_behaviour(pkg):
+    """The NEW flags of rounds 1-4: their defaults reproduce the reference (its loss, its arithmetic); the alternatives parse."""
+    w = pkg.world
+    w.configure([])
+    assert w.config['reg_rows'] == 'propagated'            # model.py:173 of THIS reference (upstream LightGCN: 'ego')
+    assert w.config['act_dtype'] == 'fp32' and w.config['gpu_shuffle'] == 1 and w.config['gpu_sampler'] == 1
+    assert w.config['prefetch_epoch'] == 1
+    w.configure(['--reg_rows', 'ego', '--act_dtype', 'fp8', '--gpu_shuffle', '0'])
+    assert (w.config['reg_rows'], w.config['act_dtype'], w.config['gpu_shuffle']) == ('ego', 'fp8', 0)
+    with pytest.raises(SystemExit):
+        w.configure(['--reg_rows', 'both'])
+    w.configure([])
+
+
+def test_table_and_mask_sizes(pkg):
+    """Pure size arithmetic of the ABI (no GPU): fp8 tables = rows + fp32 row scales padded to 256 bytes; evaluation masks =
+    one 32-bit word per (32-item tile, evaluation slot), the slots padded to 128."""
+    lib = pkg._lib.load()
+    L = pkg._lib
+    assert lib.lgcn_table_bytes(1000, 64, L.F32) == 1000 * 64 * 4 and lib.lgcn_table_bytes(1000, 64, L.BF16) == 1000 * 64 * 2
+    assert lib.lgcn_table_bytes(1000, 64, L.FP8) == (1000 * 64 + 1000 * 4 + 255) // 256 * 256
+    assert lib.lgcn_table_bytes(11_000_000, 256, L.FP8) == (11_000_000 * 260 + 255) // 256 * 256          # > 2^31: 64-bit
+    assert lib.lgcn_table_bytes(0, 64, L.FP8) == 0
+    assert lib.lgcn_eval_mask_words(40981, 29858) == ((40981 + 31) // 32) * ((29858 + 127) // 128 * 128)
+    assert lib.lgcn_eval_mask_words(0, 5) == 0 and lib.lgcn_eval_mask_words(33, 1) == 2 * 128
+
+
 def test_minibatch_and_timer(pkg):
     u = pkg.utils
     a = np.arange(10)
