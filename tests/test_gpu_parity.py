@@ -1355,6 +1355,41 @@ def test_fused_eval_kernels_vs_torch_and_oracle(pkg, oracle, tiny, lastfm, tmp_p
                                    L.tp(ev.train_idx32), 65, L.tp(topk), None, L.current_stream()) == 3      # K <= 64
 
 
+def test_procedure_test_masks_on_off_and_two_cutoffs(pkg, lastfm, tmp_path):
+    """Procedure.Test through the fused kernels with the train-positive masks precomputed (default) and with the in-sweep cursor
+    (--eval_masks 0): identical metrics; and with --topks "[20, 50]" (k = 50 stays on the fused path since round 4) against the
+    torch harness."""
+    g = lastfm
+    ds, m = _make_model(pkg, g, tmp_path)
+    users, pos, neg = pkg.Procedure.sample_epoch_to_device(ds, DEV)
+    m.fused_epoch(users, pos, neg, g.B)
+    m.eval()
+    w = pkg.world
+    res = {}
+    for masks in (1, 0):
+        w.config['eval_masks'] = masks
+        ds._lgcn_eval_index = None
+        res[masks] = pkg.Procedure.Test(ds, m, 0)
+        assert (ds._lgcn_eval_index.masks is not None) == bool(masks)
+    for k in ("precision", "recall", "ndcg"):
+        assert float(res[1][k][0]) == float(res[0][k][0]), k
+    w.config['eval_masks'] = 1
+    old_topks = list(w.topks)
+    try:
+        w.topks = [20, 50]
+        ds._lgcn_eval_index = None
+        w.config['eval_fused'] = 1
+        r_f = pkg.Procedure.Test(ds, m, 0)
+        w.config['eval_fused'] = 0
+        r_t = pkg.Procedure.Test(ds, m, 0)
+        for k in ("precision", "recall", "ndcg"):
+            assert r_f[k].shape == (2,) and np.abs(np.asarray(r_f[k], np.float64) - np.asarray(r_t[k], np.float64)).max() < 1e-9, (k, r_f[k], r_t[k])
+            assert abs(float(r_f[k][0]) - float(res[1][k][0])) < 1e-12
+    finally:
+        w.topks = old_topks
+        w.config['eval_fused'] = 1
+
+
 @pytest.mark.parametrize("which,world", [("tiny", 2), ("tiny", 3), ("lastfm", 4)])
 def test_row_sharded_step_bitwise_equals_unsharded(pkg, tiny, lastfm, tmp_path, which, world):
     """Row-sharded propagation (SURVEY 8e "beyond the contract") emulated on one GPU: `world` training
@@ -1535,6 +1570,14 @@ def test_device_shuffle_bit_exact(pkg):
     rs = np.random.RandomState(5); ref = np.arange(4097); rs.shuffle(ref)
     U.set_seed(5)
     assert np.array_equal(U.shuffle_indices_device(4097, DEV).cpu().numpy(), ref)
+    # random sizes, one continuous stream (every call starts wherever the last one left the generator block)
+    rng = np.random.Generator(np.random.PCG64(123))
+    sizes = [int(x) for x in np.concatenate([rng.integers(2, 5000, 12), rng.integers(5000, 3_000_000, 12)])]
+    U.set_seed(31)
+    want = [U.shuffle_indices(n) for n in sizes]
+    U.set_seed(31)
+    for n, w_ in zip(sizes, want):
+        assert np.array_equal(U.shuffle_indices_device(n, DEV).cpu().numpy(), w_), n
 
 
 def test_epoch_triplets_device_shuffle_equals_host_shuffle(pkg, tiny, tmp_path):
