@@ -193,13 +193,23 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # REHEARSAL HOOK (LGCN_BENCH_ONE_GPU=1): every rank on GPU 0, torch.distributed over gloo (it moves GPU tensors between the
+    # processes through the host; RCCL refuses two ranks on one device) and the per-step loop of parallel.py -- the N-rank code
+    # path of this script end to end on a one-GPU box.  Its numbers say nothing about scaling and are labelled as such.
+    one_gpu = os.environ.get("LGCN_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        os.environ["LGCN_DP_PYTHON_LOOP"] = "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dp = world > 1 or a.force_dp
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     sys.argv = [sys.argv[0]]
     pkg = importlib.import_module(PKG)
@@ -414,7 +424,8 @@ def main():
                                    f"interactions, nnz(A_hat)={nnz}, layers={K}, dim={d_full}, bpr_batch={B}",
                        "global_batch": Bg, "per_gpu_batch": (Bg + world - 1) // world, "global_steps_per_sec": steps_per_sec,
                        "triplets_per_sec": steps_per_sec * Bg, "batches_of_B_per_sec": steps_per_sec * Bg / B,
-                       "scaling_mode": a.scaling, "multi_gpu_status": "unmeasured on multi-GPU hardware by the builder (1-GPU boxes only)" if world > 1 else "n/a",
+                       "scaling_mode": a.scaling, "multi_gpu_status": ("REHEARSAL: all ranks share GPU 0, gloo collectives, per-step Python loop -- not a scaling measurement" if one_gpu else
+                                            "unmeasured on multi-GPU hardware by the builder (1-GPU boxes only)") if world > 1 else "n/a",
                        "parallelism": par,
                        "act_dtype": a.act_dtype, "xcd_remap": a.xcd_remap, "row_order": a.row_order,
                        "first_loss": first_loss, "last_loss": last_loss, "setup_seconds": setup_s},

@@ -227,7 +227,7 @@ class DataParallelBPR:
         to fall back -- through torch.distributed.  -> (count, 'library RCCL communicator' | 'torch.distributed')."""
         dev = self.model._table.device
         one = torch.ones(1, dtype=torch.float32, device=dev)
-        if dev.type == 'cuda' and self._own_communicator_ok():
+        if dev.type == 'cuda' and os.environ.get("LGCN_DP_PYTHON_LOOP") != "1" and self._own_communicator_ok():
             _lib.check(_lib.load().lgcn_dp_allreduce_sum_f32(self._communicator(), _lib.tp(one), 1, _lib.current_stream()),
                        "lgcn_dp_allreduce_sum_f32")
             return int(round(float(one.item()))), "library RCCL communicator"
