@@ -97,3 +97,55 @@ def test_two_processes_one_gpu_python_loop(tmp_path):
     work = str(tmp_path)
     mp.spawn(_worker, args=(2, _free_port(), work), nprocs=2, join=True)
     assert open(os.path.join(work, "ok.txt")).read() == "1"
+
+
+def _refusal_worker(rank, world, port, work):
+    """No LGCN_DP_PYTHON_LOOP here: DataParallelBPR really tries the library's own RCCL communicator -- and RCCL really refuses
+    (two ranks on one device: ncclCommInitRank returns "invalid usage" on both)."""
+    sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("LGCN_DP_PYTHON_LOOP", None)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.argv = [sys.argv[0]]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    pkg = importlib.import_module(PKG_NAME)
+    w = pkg.world
+    d = os.path.join(work, f"tiny_r{rank}")
+    os.makedirs(d, exist_ok=True)
+    for f in ("train.txt", "test.txt"):
+        shutil.copyfile(os.path.join(GOLDEN, "tiny", f), os.path.join(d, f))
+    B = 48
+    w.configure(["--dataset", "tiny", "--tensorboard", "0", "--bpr_batch", str(B), "--row_order", "natural",
+                 "--checkpoint_dir", os.path.join(work, f"ckpt{rank}")])
+    ds = pkg.dataloader.Loader(w.config, path=d)
+    rng = np.random.Generator(np.random.PCG64(6))
+    T = 2 * B + 5
+    U, P, N = (torch.from_numpy(rng.integers(0, hi, T).astype(np.int32)).to(dev) for hi in (ds.n_users, ds.m_items, ds.m_items))
+    pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+    ref = pkg.model.LightGCN(w.config, ds).to(dev)
+    want_loss = ref.fused_epoch(U, P, N, B).cpu().numpy()
+    want = ref._table.detach().cpu().numpy()
+    pkg.sampling.seed(2020); pkg.utils.set_seed(2020)
+    m = pkg.model.LightGCN(w.config, ds).to(dev)
+    dp = pkg.parallel.DataParallelBPR(m, w.config)
+    own = dp._own_communicator_ok()                       # collective decision: must come back False on BOTH ranks, and come back
+    got_loss = dp.train_epoch(U, P, N, B).cpu().numpy()   # ... and the epoch runs over torch.distributed's collectives instead
+    seen = dp.ranks_observed()
+    ok = (own is False and seen == (2, "torch.distributed") and np.array_equal(got_loss, want_loss)
+          and np.array_equal(m._table.detach().cpu().numpy().view(np.uint32), want.view(np.uint32)))
+    t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(os.path.join(work, "ok_refusal.txt"), "w").write(str(int(t.item())))
+    dist.destroy_process_group()
+
+
+def test_real_rccl_refusal_falls_back_on_every_rank(tmp_path):
+    """The fallback agreement of DataParallelBPR against a REAL failure of the library's communicator: two processes on one GPU, RCCL's
+    ncclCommInitRank refuses (invalid usage) on both ranks, every rank drops its communicator, nobody hangs, and the epoch runs over
+    torch.distributed -- bit for bit the single-GPU epoch (the CPU tests only simulate the failure)."""
+    work = str(tmp_path)
+    mp.spawn(_refusal_worker, args=(2, _free_port(), work), nprocs=2, join=True)
+    assert open(os.path.join(work, "ok_refusal.txt")).read() == "1"
+
