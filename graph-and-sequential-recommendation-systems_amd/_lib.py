@@ -88,6 +88,7 @@ SIGNATURES = {
     "lgcn_dp_available": (C.c_int, []),
     "lgcn_dp_unique_id": (C.c_int, [_vp]),
     "lgcn_dp_init": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lgcn_train_step_i64": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "lgcn_train_step_cols_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp), _vp]),
     "lgcn_train_step_cols_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "lgcn_dp_allreduce_sum_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),

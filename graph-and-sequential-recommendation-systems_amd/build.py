@@ -15,7 +15,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 SOURCES = [os.path.join(PKG_DIR, "csrc", f) for f in
-           ("lgcn_device.hip", "lgcn_eval.hip", "lgcn_sampler.hip", "lgcn_shuffle.hip", "lgcn_dp_loopback.hip", "lgcn_dp.cpp", "lgcn_host.cpp")]
+           ("lgcn_device.hip", "lgcn_eval.hip", "lgcn_sampler.hip", "lgcn_shuffle.hip", "lgcn_ids.hip", "lgcn_dp_loopback.hip", "lgcn_dp.cpp", "lgcn_host.cpp")]
 HEADER = os.path.join(REPO_DIR, "include", "lgcn_hip.h")
 LIB_PATH = os.environ.get("LGCN_LIB_PATH") or os.path.join(PKG_DIR, "liblgcn_hip.so")   # env: pick a tuning variant
 BASE_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"]

@@ -530,7 +530,11 @@ class LightGCN(nn.Module):
             raise RuntimeError("this configuration of the popularity gate / item-item smoothing is outside the fused step "
                                "(--fused_variants 0, or gate hidden sizes > 64 / d > 128): use BPRLoss.stageOne (autograd path)")
         dev = self._table.device
-        users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
+        # the reference's call shape: three torch.long device tensors (main.py:217-225) -- narrowed inside the step's own launch
+        # sequence (lgcn_train_step_i64) instead of three conversion kernels and allocations here
+        as_i64 = all(torch.is_tensor(t) and t.dtype == torch.int64 and t.device == dev and t.is_contiguous() for t in (users, pos, neg))
+        if not as_i64:
+            users, pos, neg = self._ids(users, dev), self._ids(pos, dev), self._ids(neg, dev)
         B = int(users.numel())
         st = self._state(max_batch=max(B, int(self.config.get('bpr_batch_size', B))), need_ctx=True,
                          dp_world=(self._dev or {}).get('dp_world', 1))
@@ -539,8 +543,14 @@ class LightGCN(nn.Module):
             lib.lgcn_ctx_set_lr(st['ctx'], float(lr))
         if loss_out is None:
             loss_out = torch.empty(3, dtype=torch.float32, device=dev)
-        _lib.check(lib.lgcn_train_step(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
-                                       _lib.tp(loss_out), _lib.current_stream()), "lgcn_train_step")
+        if as_i64:
+            if st.get('ids32') is None or st['ids32'].numel() < 3 * B:
+                st['ids32'] = torch.empty(3 * max(B, st['max_batch']), dtype=torch.int32, device=dev)
+            _lib.check(lib.lgcn_train_step_i64(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B, _lib.tp(st['ids32']),
+                                               _lib.tp(loss_out), _lib.current_stream()), "lgcn_train_step")
+        else:
+            _lib.check(lib.lgcn_train_step(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
+                                           _lib.tp(loss_out), _lib.current_stream()), "lgcn_train_step")
         self.invalidate_cache()
         return loss_out
 

@@ -80,6 +80,9 @@ def build_parser():
                         'step instead of from every triplet that names them (0 = library default 131072, < 0 = off)')
     p.add_argument('--gpu_sampler', type=int, default=1,
                    help='NEW: 1 = the cpp-mode BPR sampler runs on the GPU (same rand() stream, same rows); 0 = on the host')
+    p.add_argument('--lazy_loss', type=int, default=0,
+                   help='NEW: 1 = BPRLoss.stageOne returns a float-like DeferredLoss that is read from the device only when looked at '
+                        '(the reference returns loss.cpu().item(): a host round trip per step); 0 = a Python float, as the reference')
     p.add_argument('--gpu_shuffle', type=int, default=1,
                    help='NEW: 1 = the epoch permutation (numpy legacy shuffle: MT19937 + Fisher-Yates, same stream, same permutation) is '
                         'computed on the GPU; 0 = on the host')

@@ -101,6 +101,7 @@ def configure(argv=None):
     config['prefetch_epoch'] = args.prefetch_epoch
     config['reg_rows'] = args.reg_rows
     config['gpu_shuffle'] = args.gpu_shuffle
+    config['lazy_loss'] = args.lazy_loss
     config['eval_fused'] = args.eval_fused
     config['gpu_sampler'] = args.gpu_sampler
     config['dense_last'] = args.dense_last

@@ -247,6 +247,12 @@ int lgcn_ctx_set_dp_local(lgcn_ctx *ctx, int on);
 int lgcn_train_step(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,
                     int32_t B, float *loss_out, void *stream);
 
+/* The same step for ids as the reference passes them -- torch.long (int64) device tensors (main.py:217-225): one launch narrows the
+ * three arrays into ids_scratch (device int32 [3*B], caller-owned) and the step follows on the same stream; an id outside int32
+ * is flagged like any out-of-range id.                                                                                       */
+int lgcn_train_step_i64(lgcn_ctx *ctx, const int64_t *users, const int64_t *pos, const int64_t *neg,
+                        int32_t B, int32_t *ids_scratch, float *loss_out, void *stream);
+
 /* A whole epoch: the loop of main.py:223-225 over ceil(T/B) consecutive batches
  * of the (already shuffled) device arrays.  loss_out: [3*ceil(T/B)].           */
 int lgcn_train_epoch(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos, const int32_t *neg,

@@ -265,6 +265,50 @@ def test_upstream_loss_dp_epoch_loopback(pkg, tiny, tmp_path, world, mode):
         lib.lgcn_dp_destroy(comms[r])
 
 
+def test_stage_one_call_shapes(pkg, oracle, tiny, tmp_path):
+    """BPRLoss.stageOne the way the reference calls it -- torch.long device tensors, a Python float back (utils.py:53-64) -- goes through
+    lgcn_train_step_i64 (one launch narrows the ids inside the step); int32 tensors, numpy arrays, non-contiguous views and the
+    --lazy_loss 1 DeferredLoss take the same step: identical losses and parameters whatever the call shape; an id beyond int32 in a
+    torch.long tensor is flagged like any out-of-range id."""
+    g = tiny
+    A = (g.z["adj_indptr"], g.z["adj_indices"], g.z["adj_data"])
+    rng = np.random.Generator(np.random.PCG64(77))
+    batches = [(rng.integers(0, g.n_users, b), rng.integers(0, g.m_items, b), rng.integers(0, g.m_items, b)) for b in (64, 17, 1)]
+    results = {}
+    for shape in ("int64", "int32", "numpy", "strided", "deferred"):
+        ds, m = _make_model(pkg, g, tmp_path)
+        bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+        bpr.deferred = shape == "deferred"
+        losses = []
+        for (u, p, n) in batches:
+            if shape in ("int64", "deferred"):
+                args = tuple(torch.from_numpy(x.astype(np.int64)).to(DEV) for x in (u, p, n))
+            elif shape == "int32":
+                args = tuple(torch.from_numpy(x.astype(np.int32)).to(DEV) for x in (u, p, n))
+            elif shape == "numpy":
+                args = (u, p, n)
+            else:
+                args = tuple(torch.from_numpy(np.repeat(x.astype(np.int64), 2)).to(DEV)[::2] for x in (u, p, n))
+            r = bpr.stageOne(*args)
+            assert isinstance(r, pkg.utils.DeferredLoss) if shape == "deferred" else isinstance(r, float)
+            losses.append(float(r))
+        results[shape] = (losses, m._table.detach().cpu().numpy().copy())
+        m.check_device_errors()
+    tr = oracle.Trainer(g.n_users, *A, g.e0(), g.K, g.meta["decay"], g.meta["lr"])
+    want = [tr.stageOne(u, p, n) for (u, p, n) in batches]
+    for shape, (losses, table) in results.items():
+        assert losses == results["int64"][0] and np.array_equal(table, results["int64"][1]), shape
+    assert np.abs(np.asarray(results["int64"][0]) - np.asarray(want)).max() < 3e-6
+    np.testing.assert_allclose(results["int64"][1], tr.e0, rtol=0, atol=3e-6)
+    # an id that does not fit int32
+    ds, m = _make_model(pkg, g, tmp_path)
+    bpr = pkg.utils.BPRLoss(m, pkg.world.config)
+    u = torch.tensor([1, (1 << 40) + 3], dtype=torch.int64, device=DEV); p = torch.tensor([2, 3], dtype=torch.int64, device=DEV)
+    bpr.stageOne(u, p, p.clone())
+    with pytest.raises(pkg._lib.LgcnError):
+        m.check_device_errors()
+
+
 def test_epochs_tiny_vs_golden(pkg, tiny, tmp_path):
     """Two epochs driven exactly like main.py:215-225 through the product's own sampler,
     shuffle and fused step: triplets bit-exact, losses / parameters / Adam state vs the

@@ -249,6 +249,25 @@ def test_table_and_mask_sizes(pkg):
     assert lib.lgcn_eval_mask_words(0, 5) == 0 and lib.lgcn_eval_mask_words(33, 1) == 2 * 128
 
 
+def test_deferred_loss_is_a_number(pkg):
+    """--lazy_loss 1: what BPRLoss.stageOne returns then.  The arithmetic the reference does with the per-step loss (Procedure.py:61-68,
+    main.py:223-236: += into a float, / total_batch, :.3f) and the usual conversions, without a device."""
+    import torch
+    D = pkg.utils.DeferredLoss
+    vals = [0.5, 0.25, 1.0, 0.125]
+    tot = 0.0
+    for v in vals:
+        tot += D([torch.tensor(v)])
+    assert isinstance(tot, D) and float(tot) == sum(vals) and f"{tot / len(vals):.3f}" == f"{sum(vals) / len(vals):.3f}"
+    a, b = D([torch.tensor(0.5)]), D([torch.tensor(0.25)])
+    assert float(2 * a - 1) == 0.0 and float(1 - a) == 0.5 and float(-(a + b) * 2 + 1) == -0.5 and 1.0 / a == 2.0
+    assert b < a and a > 0.3 and a == 0.5 and max(a, b) is a and float(sum([a, b])) == 0.75
+    assert np.float64(a) == 0.5 and float(np.asarray(b)) == 0.25 and a.item() == 0.5 and repr(a) == "0.5"
+    w = pkg.world
+    w.configure(['--lazy_loss', '1']); assert w.config['lazy_loss'] == 1
+    w.configure([]); assert w.config['lazy_loss'] == 0
+
+
 def test_minibatch_and_timer(pkg):
     u = pkg.utils
     a = np.arange(10)
