@@ -18,6 +18,15 @@ _c_f32p = C.POINTER(C.c_float)
 _vp = C.c_void_p
 
 
+def fp8_col_of_byte(d):
+    """Column held by byte b of an fp8 table row (include/lgcn_hip.h, LGCN_FP8): with L = d/16 lanes per row, the 16 bytes at l*16
+    hold the four 4-column chunks j*L + l, j = 0..3  ->  int64 [d]."""
+    import numpy as np
+    b = np.arange(d)
+    l, j, e = b // 16, (b % 16) // 4, b % 4
+    return ((j * (d // 16) + l) * 4 + e).astype(np.int64)
+
+
 class TrainConfig(C.Structure):
     """Mirror of lgcn_train_config (include/lgcn_hip.h)."""
     _fields_ = [
@@ -225,7 +234,9 @@ class Graph:
         import torch
         q = tab[:n * d].view(torch.float8_e4m3fn).view(n, d).float()
         sc = tab[n * d:n * d + 4 * n].view(torch.float32)
-        return q * sc[:, None]
+        out = torch.empty_like(q)
+        out[:, torch.from_numpy(fp8_col_of_byte(d)).to(q.device)] = q           # the bytes of a row are chunk-interleaved
+        return out * sc[:, None]
 
     def spmm_fp8(self, xq, d, y_dtype=FP8):
         """A @ X for an fp8 table xq (see to_fp8): -> fp8 table (y_dtype FP8) or fp32 [n_rows, d] (F32)."""

@@ -57,7 +57,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // LGCN_FP8: a table of n rows is  n * D bytes of OCP E4M3 values  followed by  n fp32 ROW SCALES  (value = scale * fp8): one
 // pointer names both.  Scales are powers of two with max|row| / scale in [64, 128) (inside the range of both E4M3 flavours;
 // a division by a power of two is exact, so the quantisation is a pure fp8 rounding the tests restate bit for bit).
+// The columns of an fp8 row are CHUNK-INTERLEAVED: with L = D / 16 lanes per row, the 16 bytes at l*16 hold the four 4-column
+// chunks q = j*L + l (j = 0..3): byte l*16 + 4j + e = column (j*L + l)*4 + e.  A lane that gathers 16 bytes therefore owns four
+// float4 chunks that lie L chunks apart, and the fp32 side of every epilogue (G32, P / M / V, fp32 outputs) is four fully
+// coalesced float4 accesses per row instead of 64 contiguous bytes per lane (measured on the 10M x 1M graph: Adam's operands of
+// the fp8 step streamed at 4.0 TB/s with the natural order against 6.6 TB/s in the fp32 step).  The table is an opaque blob of
+// the ABI (lgcn_to_fp8 writes it, the kernels read it); lgcn_fp8_col_of_byte gives the order for anyone who decodes it.
 struct fp8_t { uint8_t v; };
+__host__ __device__ __forceinline__ int fp8_byte_of_col(int c, int D) { const int L = D / 16, q = c >> 2; return (q % L) * 16 + 4 * (q / L) + (c & 3); }
 __device__ __forceinline__ const float *fp8_scales(const void *tab, int64_t n_rows, int D) { return (const float *)((const char *)tab + n_rows * D); }
 __device__ __forceinline__ float *fp8_scales(void *tab, int64_t n_rows, int D) { return (float *)((char *)tab + n_rows * D); }
 
@@ -101,7 +108,7 @@ template <typename TI> __device__ __forceinline__ float tab_elem(const void *tab
 template <> __device__ __forceinline__ float tab_elem<float>(const void *tab, int64_t, int D, int64_t row, int col) { return ((const float *)tab)[row * D + col]; }
 template <> __device__ __forceinline__ float tab_elem<bf16_t>(const void *tab, int64_t, int D, int64_t row, int col) { return (float)((const bf16_t *)tab)[row * D + col]; }
 template <> __device__ __forceinline__ float tab_elem<fp8_t>(const void *tab, int64_t n_rows, int D, int64_t row, int col) {
-    return fp8_scales(tab, n_rows, D)[row] * fp8_decode(((const uint8_t *)tab)[row * D + col]);
+    return fp8_scales(tab, n_rows, D)[row] * fp8_decode(((const uint8_t *)tab)[row * D + fp8_byte_of_col(col, D)]);
 }
 // scale of a row whose largest magnitude is amax: 2^(e - 6) for amax = 1.f * 2^e  ->  amax / scale in [64, 128); rows
 // below 2^-100 (and zero rows) are stored as zeros with scale 1; every other finite row, up to the top of fp32, is scaled
@@ -112,8 +119,11 @@ __device__ __forceinline__ void fp8_row_scale(float amax, float &scale, float &i
 }
 // Store one row piece of C values per lane as fp8: the row's LPR = D / C lanes (contiguous, aligned, all active) agree on
 // the row maximum through xor shuffles, every lane quantises its piece, lane l == 0 writes the scale.
-template <int D, int C>
+// IL: v holds the lane's four interleaved chunks (an fp8 table was gathered: C = 16) -- its 16 bytes are contiguous at l*16;
+// otherwise v holds C consecutive columns (an fp32 / bf16 table was gathered) and every 4-column chunk goes to its own word.
+template <int D, int C, bool IL>
 __device__ __forceinline__ void store_row_fp8(void *tab, int64_t n_rows, int64_t row, int l, typename VecF<C>::T v) {
+    static_assert(!IL || C == 16, "interleaved accumulators come from fp8 gathers: 16 per lane");
     constexpr int LPR = D / C;
     float amax = 0.f;
 #pragma unroll
@@ -130,17 +140,47 @@ __device__ __forceinline__ void store_row_fp8(void *tab, int64_t n_rows, int64_t
         p = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, p, true);
         w[i] = (uint32_t)p;
     }
-    uint32_t *dst = (uint32_t *)((char *)tab + row * D + l * C);
+    if (IL) {
+        uint32_t *dst = (uint32_t *)((char *)tab + row * D + l * 16);
 #pragma unroll
-    for (int i = 0; i < C / 4; i++) dst[i] = w[i];
+        for (int i = 0; i < C / 4; i++) dst[i] = w[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < C / 4; i++) *(uint32_t *)((char *)tab + row * D + fp8_byte_of_col((l * (C / 4) + i) * 4, D)) = w[i];
+    }
     if (l == 0) fp8_scales(tab, n_rows, D)[row] = scale;
 }
 // row piece store by output type
-template <int D, int C, typename TO> struct RowStore {
-    static __device__ __forceinline__ void put(void *Y, int64_t, int64_t row, int l, typename VecF<C>::T v) { storev<C>((TO *)Y + row * D + l * C, v); }
+// a lane's piece of an fp32 row: C consecutive columns at l*C, or (IL: the accumulators of an fp8 gather) the four float4 chunks j*L + l
+template <int D, int C, bool IL> __device__ __forceinline__ typename VecF<C>::T row_load(const float *base, int64_t row, int l) {
+    if constexpr (!IL) return loadv<C>(base + row * D + l * C);
+    else {
+        typename VecF<C>::T r;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4 t = load4(base + row * D + (j * (D / 16) + l) * 4);
+            r[4 * j] = t.x; r[4 * j + 1] = t.y; r[4 * j + 2] = t.z; r[4 * j + 3] = t.w;
+        }
+        return r;
+    }
+}
+template <int D, int C, bool IL> __device__ __forceinline__ void row_store(float *base, int64_t row, int l, typename VecF<C>::T v) {
+    if constexpr (!IL) storev<C>(base + row * D + l * C, v);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) store4(base + row * D + (j * (D / 16) + l) * 4, f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]});
+    }
+}
+template <int D, int C, typename TO, bool IL> struct RowStore {
+    static __device__ __forceinline__ void put(void *Y, int64_t, int64_t row, int l, typename VecF<C>::T v) {
+        static_assert(!IL, "an fp8 gather writes fp32 or fp8");
+        storev<C>((TO *)Y + row * D + l * C, v); }
 };
-template <int D, int C> struct RowStore<D, C, fp8_t> {
-    static __device__ __forceinline__ void put(void *Y, int64_t n_rows, int64_t row, int l, typename VecF<C>::T v) { store_row_fp8<D, C>(Y, n_rows, row, l, v); }
+template <int D, int C, bool IL> struct RowStore<D, C, float, IL> {
+    static __device__ __forceinline__ void put(void *Y, int64_t, int64_t row, int l, typename VecF<C>::T v) { row_store<D, C, IL>((float *)Y, row, l, v); }
+};
+template <int D, int C, bool IL> struct RowStore<D, C, fp8_t, IL> {
+    static __device__ __forceinline__ void put(void *Y, int64_t n_rows, int64_t row, int l, typename VecF<C>::T v) { store_row_fp8<D, C, IL>(Y, n_rows, row, l, v); }
 };
 __device__ __forceinline__ bool bit_set(const uint32_t *bm, int i) { return (bm[i >> 5] >> (i & 31)) & 1u; }
 
@@ -434,28 +474,37 @@ enum { M_SPARSE = 1, M_ADDG = 2, M_ADAM = 4, M_ADDSELF = 8 };
 // Adam's operands of one row piece, fetched under the LAST gather batch of a pack (see pack_batch)
 template <int C> struct AdamPre { typename VecF<C>::T p, m, v; bool have; };
 
-template <int D, typename TO, int MODE, int C>
+// IL: the accumulators are the four interleaved chunks of an fp8 gather (see fp8_t): the fp32 rows are addressed chunk by chunk
+template <int D, typename TO, int MODE, int C, bool IL = false>
 __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, int l, typename VecF<C>::T acc, bool flagged,
                                               const AdamPre<C> *pre = nullptr) {
     typedef typename VecF<C>::T V;
     const int64_t off = row * D + l * C;
-    if (MODE & M_ADDSELF) acc = loadv<C>(a.selfX + off) + acc;
+    if (MODE & M_ADDSELF) acc = row_load<D, C, IL>(a.selfX, row, l) + acc;
     if ((MODE & M_ADDG) && flagged) {      // (the row's bitmap word was fetched before the gathers -- a dependent load here measured +0.3-0.6 % on the step)
-        V g = loadv<C>(a.G32 + off);          // = (float)(G64 * 2^-50) / (K+1), converted once by k_g32
+        V g = row_load<D, C, IL>(a.G32, row, l);          // = (float)(G64 * 2^-50) / (K+1), converted once by k_g32
         acc = g + acc;
         if ((MODE & M_ADAM) && !(MODE & M_SPARSE) && a.clear) {      // consumed: leave the workspace clean
             // (the bitmap is NOT cleared here: an atomic on words that every row's epilogue reads keeps
             //  dropping those lines from L2 -- measured +22 us; the two bitmaps alternate per step and
             //  k_triplet of the next step zeroes the stale one with plain stores)
-            i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
+            if constexpr (IL) {
 #pragma unroll
-            for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
+                for (int j = 0; j < 4; j++) {
+                    i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + row * D + (j * (D / 16) + l) * 4);
+                    q[0] = i64x2{0, 0}; q[1] = i64x2{0, 0};
+                }
+            } else {
+                i64x2 *q = reinterpret_cast<i64x2 *>(a.G64 + off);
+#pragma unroll
+                for (int i = 0; i < C / 2; i++) q[i] = i64x2{0, 0};
+            }
         }
     }
     if (MODE & M_ADAM) {
         V p, m, v;
         if (pre && pre->have) { p = pre->p; m = pre->m; v = pre->v; }
-        else { p = loadv<C>(a.P + off); m = loadv<C>(a.M + off); v = loadv<C>(a.V + off); }
+        else { p = row_load<D, C, IL>(a.P, row, l); m = row_load<D, C, IL>(a.M, row, l); v = row_load<D, C, IL>(a.V, row, l); }
         if ((MODE & M_ADDG) && a.cnt && flagged) {
             // upstream LightGCN's L2 term (cfg.reg_ego): d(decay * reg)/dE0[row] = decay/B * (slots naming the row) * E0[row],
             // added to the propagated gradient here, where E0[row] is in registers anyway
@@ -469,11 +518,11 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int64_t row, in
 #pragma unroll
         for (int i = 0; i < C; i++) denom[i] = sqrtf(v[i]) / a.bc2_sqrt + a.eps;
         p = p - a.step_size * (m / denom);              // addcdiv_(exp_avg, denom, -step_size)
-        storev<C>(a.P + off, p); storev<C>(a.M + off, m); storev<C>(a.V + off, v);
-        if (a.Pb) storev<C>(a.Pb + off, p);
-        if (a.Pq) store_row_fp8<D, C>(a.Pq, a.n_rows, row, l, p);
+        row_store<D, C, IL>(a.P, row, l, p); row_store<D, C, IL>(a.M, row, l, m); row_store<D, C, IL>(a.V, row, l, v);
+        if (a.Pb) storev<C>(a.Pb + off, p);          // (bf16 shadow: only with bf16 tables, never IL)
+        if (a.Pq) store_row_fp8<D, C, IL>(a.Pq, a.n_rows, row, l, p);
     } else {
-        RowStore<D, C, TO>::put(a.Y, a.n_rows, row, l, acc);
+        RowStore<D, C, TO, IL>::put(a.Y, a.n_rows, row, l, acc);
     }
 }
 
@@ -621,6 +670,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
     typedef typename G::Acc Acc;
     typedef Raw<TI, SP> R;
     constexpr int LPR = G::LPR, NPW = G::NPW, C = G::CPL;
+    constexpr bool IL = !SP && sizeof(TI) == 1;        // accumulators of an fp8 gather: chunk-interleaved columns
     constexpr int GPR = RowGeo<D, TI, SP>::GPR, RPK = RowGeo<D, TI, SP>::RPK;
     static_assert(GPR == 1 || GPR == 2 || GPR == 4, "one, two or four lane groups per row");
     static_assert(LPR * GPR <= 64 && (GPR == 1 || LPR >= 4), "lane groups of a row must fit the wave");
@@ -664,7 +714,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
         const bool rflag = (MODE & M_ADDG) ? bit_set(a.bitmap, (int)row) : false;
         Acc acc = row_gather<D, TI, SP, BIG>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
         if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
-            if (lane < LPR) spmm_epilogue<D, TO, MODE, C>(a, row, lane, acc, rflag);
+            if (lane < LPR) spmm_epilogue<D, TO, MODE, C, IL>(a, row, lane, acc, rflag);
             return;
         }
         // Publish the partial WRITE-THROUGH (sc1: 8-byte agent-scope stores, no release fence -- a
@@ -696,7 +746,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
             for (int i = 0; i < C / 2; i++) pk.q[i] = __hip_atomic_load(sp_ + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k == 0) tot = pk.v; else tot += pk.v;
         }
-        spmm_epilogue<D, TO, MODE, C>(a, row, lane, tot, rflag);
+        spmm_epilogue<D, TO, MODE, C, IL>(a, row, lane, tot, rflag);
         return;
     }
     // ---- short rows (<= 64 non-zeros): a pack of NPW rows at a time, ONE ROW PER LANE GROUP.  All
@@ -826,7 +876,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
             for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
         }
         const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
-        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C>(a, mrow, l, acc, mflag, PRE ? &pre : nullptr);
+        if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C, IL>(a, mrow, l, acc, mflag, PRE ? &pre : nullptr);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
 }
@@ -842,9 +892,10 @@ struct MeanArgs {
 // piece i (4 consecutive elements) of an [N,d] table of TI
 template <typename TI> __device__ __forceinline__ f32x4 tab_load4(const void *tab, int64_t i, int d, int64_t N) { return load4((const TI *)tab + i * 4); }
 template <> __device__ __forceinline__ f32x4 tab_load4<fp8_t>(const void *tab, int64_t i, int d, int64_t N) {
-    const int w = ((const int *)tab)[i];
+    const int64_t row = (i * 4) / d;
+    const int w = *(const int *)((const char *)tab + row * d + fp8_byte_of_col((int)(i * 4 - row * d), d));      // a 4-column chunk is one aligned word
     const auto a = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
-    const float sc = ((const float *)((const char *)tab + N * d))[(i * 4) / d];
+    const float sc = ((const float *)((const char *)tab + N * d))[row];
     return f32x4{a[0] * sc, a[1] * sc, b[0] * sc, b[1] * sc};
 }
 
@@ -875,8 +926,8 @@ __global__ void __launch_bounds__(256) k_to_fp8(const float *src, void *dst, int
     const int64_t rows_pad = (n_rows + RPB - 1) / RPB * RPB;          // whole lane groups stay together (the shuffles need them)
     for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < rows_pad; r += (int64_t)gridDim.x * RPB) {
         const int64_t row = r < n_rows ? r : n_rows - 1;
-        const f32x16 v = loadv<16>(src + row * D + l * 16);
-        if (r < n_rows) store_row_fp8<D, 16>(dst, n_rows, row, l, v);
+        const f32x16 v = row_load<D, 16, true>(src, row, l);          // the lane's four chunks j*L + l: coalesced float4 loads
+        if (r < n_rows) store_row_fp8<D, 16, true>(dst, n_rows, row, l, v);
         else { float amax = 0.f; for (int o = 1; o < LPR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o)); }   // (keep the group's shuffles matched)
     }
 }
@@ -1124,7 +1175,12 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
         const int u0 = NW == 4 ? ((w - c + 4) & 3) : ((w - c + 3) % 3), units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
         if (u0 < units) {
             const typename G::Acc x = units_gather<D, TG, BIG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
-            if (lane < LPR) storev<C>(&part[c][w][lane * C], x);
+            if (lane < LPR) {
+                if constexpr (sizeof(TG) == 1) {       // an fp8 gather: the lane's values are the chunks j*LPR + lane (see fp8_t)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) store4(&part[c][w][(j * LPR + lane) * 4], f32x4{x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]});
+                } else storev<C>(&part[c][w][lane * C], x);
+            }
             any = true;
         }
     }

@@ -30,7 +30,10 @@ extern "C" {
 /* storage type of propagated activations (accumulation is always fp32) */
 enum { LGCN_F32 = 0, LGCN_BF16 = 1, LGCN_FP8 = 2 };
 /* LGCN_FP8: a table of n rows is n*d bytes of OCP E4M3 values FOLLOWED BY n fp32 row scales (value = scale * fp8), one pointer
- * for both; scales are powers of two with max|row| / scale in [64, 128).  d must be 64, 128 or 256.  Accumulation is fp32 as
+ * for both; scales are powers of two with max|row| / scale in [64, 128).  d must be 64, 128 or 256.  The bytes of a row are
+ * CHUNK-INTERLEAVED (an opaque layout: lgcn_to_fp8 writes it, the kernels read it): with L = d/16, byte l*16 + 4j + e holds
+ * column (j*L + l)*4 + e, so that a lane gathering 16 bytes owns four float4 chunks L chunks apart and the fp32 side of every
+ * epilogue is coalesced.  Accumulation is fp32 as
  * with every storage type.  lgcn_table_bytes: bytes of one [n_rows, d] table of a storage type (fp8: rows + scales, padded
  * to 256); lgcn_to_fp8: quantise an fp32 table (device pointers).                                                     */
 int64_t lgcn_table_bytes(int64_t n_rows, int32_t d, int32_t dtype);

@@ -39,8 +39,13 @@ def decode(bytes_, scale):
 
 
 def table_parts(pkg, tab, n, d):
+    """(bytes in COLUMN order [n, d], scales [n]) of a library fp8 table: the bytes of a row are stored chunk-interleaved
+    (byte l*16 + 4j + e = column (j*d/16 + l)*4 + e: what makes the fp32 side of the kernels' epilogues coalesced)."""
     t = tab.cpu()
-    return t[:n * d].view(n, d).numpy(), t[n * d:n * d + 4 * n].view(torch.float32).numpy()
+    raw = t[:n * d].view(n, d).numpy()
+    nat = np.empty_like(raw)
+    nat[:, pkg._lib.fp8_col_of_byte(d)] = raw
+    return nat, t[n * d:n * d + 4 * n].view(torch.float32).numpy()
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
@@ -69,6 +74,8 @@ def test_fp8_quantiser_bit_exact_vs_torch(pkg, d):
     big[6] = False
     assert (np.abs(dec - X)[big] <= 2.0 ** -4 * np.abs(X)[big]).all()
     assert np.array_equal(pkg._lib.Graph.from_fp8(tab, n, d).cpu().numpy(), dec)
+    order = pkg._lib.fp8_col_of_byte(d)
+    assert sorted(order.tolist()) == list(range(d)) and order[0] == 0 and order[4] == (d // 16) * 4 and order[16] == 4
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
