@@ -599,11 +599,11 @@ __device__ __forceinline__ void reduce_loss_wave(const float *terms, const float
 // entries (written once per pack), so a gather costs its address, its load and its multiply-adds and nothing else
 // (before: clamp, select, compare, select, LDS address and a 64-bit address per gathered row -- 9 of the 12 / 21 vector
 // instructions per fp32 / bf16 gather; loads are unconditional either way: a predicated load makes hipcc wait).
-template <int D, typename TI, bool SPARSE, int U, int GPR, bool PRE, bool BIG>
+template <int D, typename TI, bool SPARSE, int U, int GPR, bool PRE, bool BIG, int PC>
 __device__ __forceinline__ void pack_batch(const int2 *p, const GatherSrc &src, int l,
                                            typename Geo<D, TI, SPARSE>::Acc &acc,
                                            const SpmmArgs *a, int64_t off, bool final_batch,
-                                           AdamPre<Geo<D, TI, SPARSE>::CPL> *pre) {
+                                           AdamPre<PC> *pre) {
     typedef Raw<TI, SPARSE> R;
     int2 cv[U]; typename R::T xr[U];
 #pragma unroll
@@ -611,8 +611,7 @@ __device__ __forceinline__ void pack_batch(const int2 *p, const GatherSrc &src, 
 #pragma unroll
     for (int u = 0; u < U; u++) xr[u] = R::template load<BIG>(src, cv[u].x, D, l);
     if (PRE && final_batch && off >= 0) {       // the pack's last gathers are in flight: Adam's operands ride the same round trip
-        constexpr int C = Geo<D, TI, SPARSE>::CPL;
-        pre->p = loadv<C>(a->P + off); pre->m = loadv<C>(a->M + off); pre->v = loadv<C>(a->V + off);
+        pre->p = loadv<PC>(a->P + off); pre->m = loadv<PC>(a->M + off); pre->v = loadv<PC>(a->V + off);
         pre->have = true;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -634,6 +633,12 @@ template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAV
 // shorter waves are what this kernel wants (measured): two groups per bf16 row = 4 rows per wave like fp32.
 #ifndef SPMM_GPR_BF16
 #define SPMM_GPR_BF16 2
+#endif
+#ifndef SPMM_ADAM_SPLIT
+#define SPMM_ADAM_SPLIT 1     /* bf16 tables: the two lane groups of a row share its Adam epilogue (see k_spmm) */
+#endif
+#ifndef SPMM_ADAM_PREFETCH_BF16
+#define SPMM_ADAM_PREFETCH_BF16 0
 #endif
 #ifndef SPMM_GPR_F32
 #define SPMM_GPR_F32 1
@@ -861,11 +866,14 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
         const int mrow = __shfl(my_row, myr);
         // (fp32 tables only: with a bf16 table the kernel is already at its register budget and the operands spill --
         //  measured 6940 vs 7420 steps/s; fp32: 6339 vs 6306)
-        constexpr bool PRE = SPMM_ADAM_PREFETCH && (MODE & M_ADAM) != 0 && sizeof(TI) == 4;
-        AdamPre<C> pre; pre.have = false;
-        const int64_t poff = (PRE && mrow >= 0 && sub == 0) ? (int64_t)mrow * D + l * C : -1;
+        //  with the two lane groups of a bf16 row sharing the epilogue -- SPLIT below -- the operands are 12 registers, not 24)
+        constexpr bool SPLIT = SPMM_ADAM_SPLIT && (MODE & M_ADAM) != 0 && C == 8 && GPR == 2 && !IL;
+        constexpr bool PRE = SPMM_ADAM_PREFETCH && (MODE & M_ADAM) != 0 && (sizeof(TI) == 4 || (SPLIT && SPMM_ADAM_PREFETCH_BF16));
+        constexpr int PC = SPLIT ? 4 : C;
+        AdamPre<PC> pre; pre.have = false;
+        const int64_t poff = (PRE && mrow >= 0 && (SPLIT || sub == 0)) ? (int64_t)mrow * D + (SPLIT ? (2 * l + sub) * 4 : l * C) : -1;
         int u0 = 0;
-#define PACK_BATCH(UU) pack_batch<D, TI, SP, UU, GPR, PRE, BIG>(mystage + GPR * u0, src, l, acc, &a, poff, maxcnt - u0 <= UU, &pre)
+#define PACK_BATCH(UU) pack_batch<D, TI, SP, UU, GPR, PRE, BIG, PC>(mystage + GPR * u0, src, l, acc, &a, poff, maxcnt - u0 <= UU, &pre)
         if (U >= 8) for (; maxcnt - u0 > 4; u0 += 8) PACK_BATCH((U >= 8 ? 8 : U));
         if (U >= 4) for (; maxcnt - u0 > 2; u0 += 4) PACK_BATCH((U >= 4 ? 4 : U));
         for (; maxcnt - u0 > 1; u0 += 2) PACK_BATCH(2);
@@ -876,6 +884,16 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
             for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
         }
         const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
+        if constexpr (SPLIT) {
+            // bf16 table, Adam: both lane groups of the row hold its sums, so BOTH run the fp32 epilogue, group `sub`
+            // on the 4-column chunk 2l + sub.  One float4 per operand and lane, whole 64-byte lines per instruction
+            // (8 columns per lane = two instructions that each touch every line of the row and use half of it);
+            // the same arithmetic per element, so the same bits.
+            if (mrow >= 0) {
+                const f32x4 h = sub ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{acc[0], acc[1], acc[2], acc[3]};
+                spmm_epilogue<D, TO, MODE, 4, false>(a, mrow, 2 * l + sub, h, mflag, PRE ? &pre : nullptr);
+            }
+        } else
         if (mrow >= 0 && sub == 0) spmm_epilogue<D, TO, MODE, C, IL>(a, mrow, l, acc, mflag, PRE ? &pre : nullptr);
         if (PACKS > 1) __builtin_amdgcn_wave_barrier();
     }
