@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 F32, BF16, FP8 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_LAYERS = 8
 
 _c_i32p = C.POINTER(C.c_int32)
@@ -86,6 +86,7 @@ SIGNATURES = {
     "lgcn_dp_block_floats": (C.c_int64, [_vp, C.c_int32, C.c_int32]),
     "lgcn_train_step_dp_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "lgcn_train_step_dp_dense_part1": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "lgcn_ctx_gate_total": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "lgcn_train_step_dp_part2": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "lgcn_ctx_check": (C.c_int, [_vp, _vp]),
     "lgcn_eval_topk": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),

@@ -1663,6 +1663,7 @@ __global__ void __launch_bounds__(256) k_flag_rows(SlotArgs a) {
     if (row >= 0) {
         atomicOr(a.bitmap + (row >> 5), 1u << (row & 31));
         if (a.cnt) atomicAdd(a.cnt + row, 1);          // dense form: every rank counts the whole global batch itself (part 1 does not)
+        if (a.item_bitmap && s >= a.B) { const int64_t it = row - a.n_users; atomicOr(a.item_bitmap + (it >> 5), 1u << (it & 31)); }
     }
 }
 
@@ -2119,6 +2120,8 @@ struct lgcn_ctx {
     float *tvar;                  // [N,d] fp32 final propagated table T (library-owned)
     uint32_t *item_bitmap;        // [ceil(m_items/32)] items named by the batch (item-item backward), library-owned
     long long *gate_partials;     // [n_wg, P] parameter-gradient partial sums, fixed point (library-owned)
+    long long *gate_total;        // [P] this rank's sum of them, all-reduced by the dense data-parallel form (behind gate_partials)
+    bool gate_total_live;         // the next backward takes the MLP gradient from gate_total
     int32_t gate_P, gate_wgs;
     int32_t *cnt;                 // reg_ego: [N] slots of the running step naming each row (library-owned, zero between steps)
     float *colsum;                // [3 * max_batch] partial scores / reg terms of a column-sharded step (library-owned)
@@ -2165,7 +2168,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
     x->g32 = nullptr; x->e0b = nullptr; x->e0q = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
     x->hub_graph = nullptr; x->hub_nnz = 0; x->hub_rows = 0;
-    x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_P = 0; x->gate_wgs = 0;
+    x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_total = nullptr; x->gate_total_live = false; x->gate_P = 0; x->gate_wgs = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
     if (ok) ok = hipMalloc((void **)&x->colsum, sizeof(float) * 3 * (size_t)c.max_batch) == hipSuccess;
@@ -2178,7 +2181,8 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     if (ok && gate) {
         x->gate_P = 2 * c.pop_hidden + c.d * c.pop_hidden + c.d + 2 * c.d * c.gate_hidden + 2 * c.gate_hidden + 1;
         x->gate_wgs = (c.max_batch + GATE_TPB - 1) / GATE_TPB;
-        ok = hipMalloc((void **)&x->gate_partials, sizeof(long long) * (size_t)x->gate_wgs * x->gate_P) == hipSuccess;
+        ok = hipMalloc((void **)&x->gate_partials, sizeof(long long) * ((size_t)x->gate_wgs + 1) * x->gate_P) == hipSuccess;
+        if (ok) x->gate_total = x->gate_partials + (size_t)x->gate_wgs * x->gate_P;
     }
     if (ok && c.act_dtype == LGCN_BF16 && c.K >= 2) ok = hipMalloc((void **)&x->e0b, gbytes / 2) == hipSuccess;
     if (ok && c.act_dtype == LGCN_FP8 && c.K >= 2) ok = hipMalloc(&x->e0q, table_bytes(x->N, c.d, LGCN_FP8)) == hipSuccess;
@@ -2533,6 +2537,8 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         GateAdamArgs ga{};
         if (gathered) {      // data parallel: the ranks' totals sit in the tails of their exchange blocks
             ga.src = (const long long *)(gathered + dp_block_tail(x, shard)); ga.n_src = world; ga.stride = dp_block_floats(x, shard) / 2;
+        } else if (x->gate_total_live) {      // dense form: the all-reduced total
+            ga.src = x->gate_total; ga.n_src = 1; ga.stride = x->gate_P; x->gate_total_live = false;
         } else { ga.src = x->gate_partials; ga.n_src = (B + GATE_TPB - 1) / GATE_TPB; ga.stride = x->gate_P; }
         ga.P = x->gate_P;
         ga.params = c.gate_params; ga.m = c.gate_adam_m; ga.v = c.gate_adam_v; ga.grad_out = c.gate_grad;
@@ -2612,7 +2618,6 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
                                               int32_t B_global, int32_t world, int32_t rank, void *stream) {
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
-    if (x->variant) { lgcn_set_error("dp step: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("dp step: bad world/rank"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
     const int32_t b_off = rank * shard;
@@ -2620,15 +2625,35 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
     if (B_local > shard) B_local = shard;
     if (B_local < 0) B_local = 0;
     hipStream_t st = (hipStream_t)stream;
-    // this rank owns positions [b_off, b_off+B_local) of the global loss-term arrays; the rest must be zero
-    HIP_OK(hipMemsetAsync(x->c.terms, 0, sizeof(float) * 2 * (size_t)B_global, st));
+    const bool gate = x->variant && x->c.item_pop;
+    // this rank owns positions [b_off, b_off+B_local) of the global loss-term arrays (loss | reg | with the gate: entropy);
+    // the rest must be zero
+    HIP_OK(hipMemsetAsync(x->c.terms, 0, sizeof(float) * (gate ? 3 : 2) * (size_t)B_global, st));
     if ((rc = run_forward(x, st))) return rc;
-    if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st, false))) return rc;
+    if (x->variant) {
+        // optional branches: the shard's rows go into this rank's G64 by atomics like the default model's; the MLP
+        // parameter gradients of the shard are summed (fixed point: any order) into gate_total, one more all-reduce
+        if ((rc = run_variant_loss(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st))) return rc;
+        if (gate) {
+            if (B_local > 0)
+                hipLaunchKernelGGL(k_gate_rank_total, dim3((unsigned)((x->gate_P + 255) / 256)), dim3(256), 0, st,
+                                   (const long long *)x->gate_partials, (int32_t)((B_local + GATE_TPB - 1) / GATE_TPB), x->gate_P, x->gate_total);
+            else HIP_OK(hipMemsetAsync(x->gate_total, 0, sizeof(long long) * (size_t)x->gate_P, st));
+            x->gate_total_live = true;
+        }
+    } else if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st, false))) return rc;
     SlotArgs s{};
     s.users = users; s.pos = pos; s.neg = neg; s.B = B_global; s.n_users = x->c.n_users; s.N = x->N;
     s.bitmap = x->c.bitmap + x->flip * x->bm_words; s.cnt = x->cnt;
+    s.item_bitmap = (x->variant && x->c.i2i) ? x->item_bitmap : nullptr;      // the smoothing's backward reads the items of the GLOBAL batch
     hipLaunchKernelGGL(k_flag_rows, dim3((3 * B_global + 255) / 256), dim3(256), 0, st, s);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lgcn_ctx_gate_total(const lgcn_ctx *x, void **buf, int32_t *count) {
+    if (!x || !buf || !count) { lgcn_set_error("lgcn_ctx_gate_total: null argument"); return 3; }
+    *buf = x->gate_total; *count = x->gate_total ? x->gate_P : 0;
     return 0;
 }
 
@@ -2824,7 +2849,9 @@ static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, c
         } else {
             if ((rc = lgcn_train_step_dp_dense_part1(x, users + t, pos + t, neg + t, b, world, rank, stream))) return rc;
             r = api->AllReduce(x->c.G64, x->c.G64, (size_t)x->N * x->c.d, ncclInt64, ncclSum, dp->comm, st);
-            if (r == ncclSuccess) r = api->AllReduce(x->c.terms, x->c.terms, (size_t)2 * b, ncclFloat32, ncclSum, dp->comm, st);
+            const bool gate = x->variant && x->c.item_pop;
+            if (r == ncclSuccess) r = api->AllReduce(x->c.terms, x->c.terms, (size_t)(gate ? 3 : 2) * b, ncclFloat32, ncclSum, dp->comm, st);
+            if (r == ncclSuccess && gate) r = api->AllReduce(x->gate_total, x->gate_total, (size_t)x->gate_P, ncclInt64, ncclSum, dp->comm, st);
             if (r != ncclSuccess) { lgcn_set_error("ncclAllReduce failed"); return 11; }
             if ((rc = lgcn_train_step_dp_part2(x, users + t, pos + t, neg + t, b, world, nullptr, loss_out + 3 * i, stream))) return rc;
         }

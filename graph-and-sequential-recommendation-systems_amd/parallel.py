@@ -99,10 +99,10 @@ def column_shard(model_cls, config, dataset, world, rank, device):
 
 
 class _DevArray:
-    """a device float32 buffer the library owns, as something torch.as_tensor can wrap (no copy)"""
+    """a device buffer the library owns (float32, or int64 with typestr '<i8'), as something torch.as_tensor can wrap (no copy)"""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, n, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 def exchange_rows(buf, ranges, group=None):
@@ -134,11 +134,11 @@ class DataParallelBPR:
         from .utils import _AdamView
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        # (the dense all-reduce, row-sharded and column-sharded modes refuse the optional branches: the first two were never wired to
-        #  carry the MLP gradients, the third cannot -- the gate's MLPs mix the columns of a row)
-        if getattr(recmodel, 'has_variants', False) and not (getattr(recmodel, 'fused_variants', False) and reduce == 'rows' and shard == 'batch'):
+        # (row-sharded and column-sharded propagation refuse the optional branches: the first was never wired to carry the smoothing's
+        #  extra exchange, the second cannot -- the gate's MLPs mix the columns of a row)
+        if getattr(recmodel, 'has_variants', False) and not (getattr(recmodel, 'fused_variants', False) and shard == 'batch'):
             raise NotImplementedError("with the popularity gate / item-item smoothing, data-parallel training needs the fused step "
-                                      "(--fused_variants 1) and the gradient-row exchange: reduce='rows', shard='batch'")
+                                      "(--fused_variants 1) and batch sharding: shard='batch' (reduce='rows' or 'dense')")
         self.model = recmodel
         self.group = group
         self.world = dist.get_world_size(group)
@@ -348,7 +348,11 @@ class DataParallelBPR:
                                                           self.world, self.rank, stream),
                        "lgcn_train_step_dp_dense_part1")
             dist.all_reduce(st['G64'], op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(st['terms'][:2 * B], op=dist.ReduceOp.SUM, group=self.group)
+            gp, gn = C.c_void_p(), C.c_int32()
+            _lib.check(lib.lgcn_ctx_gate_total(st['ctx'], C.byref(gp), C.byref(gn)), "lgcn_ctx_gate_total")
+            dist.all_reduce(st['terms'][:(3 if gn.value else 2) * B], op=dist.ReduceOp.SUM, group=self.group)
+            if gn.value:        # popularity gate: the ranks' fixed-point sums of the MLP parameter gradients
+                dist.all_reduce(torch.as_tensor(_DevArray(gp.value, gn.value, "<i8"), device=dev), op=dist.ReduceOp.SUM, group=self.group)
             gptr = None
         _lib.check(lib.lgcn_train_step_dp_part2(st['ctx'], _lib.tp(users), _lib.tp(pos), _lib.tp(neg), B,
                                                 self.world, gptr, _lib.tp(loss), stream),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LGCN_ABI_VERSION 10
+#define LGCN_ABI_VERSION 11
 #define LGCN_MAX_LAYERS 8
 
 /* storage type of propagated activations (accumulation is always fp32) */
@@ -284,10 +284,15 @@ int lgcn_train_step_dp_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t 
  *    is flagged for the whole global batch on every rank and needs no collective)
  *   part 2 with gathered == NULL: backward + Adam from the reduced G64.
  * Integer sums commute, so this is again bitwise equal to lgcn_train_step -- but it moves
- * N*d*8 bytes per step (Gowalla 36 MB) instead of 1.6 MB.                                */
+ * N*d*8 bytes per step (Gowalla 36 MB) instead of 1.6 MB.
+ * With the popularity gate on, terms carries a third block (the gates' entropy: all-reduce 3*B_global
+ * floats) and the rank's fixed-point sums of the MLP parameter gradients sit in the buffer
+ * lgcn_ctx_gate_total names (int64[count]): all-reduce SUM it too before part 2.
+ * (the reference trains on one device: model.py:139-157,176-181 define what is summed)      */
 int lgcn_train_step_dp_dense_part1(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
                                    const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,
                                    void *stream);
+int lgcn_ctx_gate_total(const lgcn_ctx *ctx, void **buf, int32_t *count);   /* count 0 without the gate */
 int lgcn_train_step_dp_part2(lgcn_ctx *ctx, const int32_t *users, const int32_t *pos,
                              const int32_t *neg, int32_t B_global, int32_t world,
                              const float *gathered, float *loss_out, void *stream);

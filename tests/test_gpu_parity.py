@@ -593,10 +593,12 @@ def test_dp_cols_epoch_loopback(pkg, tiny, tmp_path, world, d, act, reg_rows):
         lib.lgcn_dp_destroy(comms[r])
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
-def test_dp_epoch_optional_branches_loopback(pkg, tiny, tmp_path, tag, world):
-    """The popularity gate / item-item smoothing under data parallelism (gradient-row exchange): W threads, each with its own model
+def test_dp_epoch_optional_branches_loopback(pkg, tiny, tmp_path, tag, world, mode):
+    """The popularity gate / item-item smoothing under data parallelism -- mode 0: gradient-row exchange; mode 1: the dense form
+    (all-reduce of G64, of the loss / reg / ENTROPY terms and of the fixed-point MLP gradient sums).  W threads, each with its own model
     (own MLP parameter buffer, own item-item graphs), context, stream and loopback communicator run lgcn_train_epoch_dp; the exchange
     block carries the gradient rows, the loss / reg / ENTROPY terms and the rank's fixed-point sums of the MLP parameter gradients.
     Ragged shards (the batch is not a multiple of the world, nor the shard of the 8 triplets a gate workgroup handles) and an empty
@@ -647,7 +649,7 @@ def test_dp_epoch_optional_branches_loopback(pkg, tiny, tmp_path, tag, world):
     rcs, errs = [None] * world, [None] * world
 
     def rank_main(r):
-        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, 0, None, L.tp(gathered[r]),
+        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, mode, None, L.tp(gathered[r]),
                                          L.tp(losses[r]), C.c_void_p(streams[r].cuda_stream))
         if rcs[r]:
             errs[r] = lib.lgcn_last_error()
@@ -667,10 +669,13 @@ def test_dp_epoch_optional_branches_loopback(pkg, tiny, tmp_path, tag, world):
         m.check_device_errors()
     for r in range(world):
         lib.lgcn_dp_destroy(comms[r])
-    # dense all-reduce and row-sharded propagation refuse a context with a branch on
+    # row-sharded and column-sharded propagation refuse a context with a branch on
     st = models[0]._dev
-    rc = lib.lgcn_train_step_dp_dense_part1(st['ctx'], L.tp(U), L.tp(P), L.tp(Nn), B, world, 0, L.current_stream())
-    assert rc != 0
+    assert lib.lgcn_rs_phase(st['ctx'], 0, 1, L.tp(U), L.tp(P), L.tp(Nn), B, world, 0, None, None, L.current_stream()) != 0
+    assert lib.lgcn_train_step_cols_part1(st['ctx'], L.tp(U), L.tp(P), L.tp(Nn), B, None, L.current_stream()) != 0
+    gp, gn = C.c_void_p(), C.c_int32()
+    L.check(lib.lgcn_ctx_gate_total(st['ctx'], C.byref(gp), C.byref(gn)), "gate_total")
+    assert (gn.value > 0 and gp.value) if meta["use_pop_gate"] else gn.value == 0
     w.configure([])
 
 

@@ -87,6 +87,35 @@ def _worker(rank, world, port, work):
     dist.all_gather_object(box, {k: float(v[0]) for k, v in r.items()})
     ok = ok and box[0] == box[1]
     mc.check_device_errors()
+    # the fork's optional branches (popularity gate + item-item smoothing) through the per-step loop, both batch-sharded forms:
+    # the dense one all-reduces G64, three blocks of terms and the library-owned int64 array of MLP gradient sums
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "tiny", "golden_gate_i2i.json")))
+    w.configure([])
+    w.dataset = "tiny"
+    w.config.update({'lightGCN_n_layers': meta["K"], 'latent_dim_rec': meta["d"], 'bpr_batch_size': B, 'decay': meta["decay"], 'lr': meta["lr"],
+                     'use_pop_gate': meta["use_pop_gate"], 'use_item_item': meta["use_item_item"],
+                     'i2i_path': os.path.join(GOLDEN, "tiny", "i2i_tiny.npz"), 'i2i_alpha': meta["i2i_alpha"], 'fused_variants': 1,
+                     'checkpoint_dir': os.path.join(work, f"ckptv{rank}")})
+    dsv = pkg.dataloader.Loader(w.config, path=d)
+
+    def fresh_v():
+        pkg.utils.set_seed(meta["seed"])
+        mv = pkg.model.LightGCN(w.config, dsv).to(dev)
+        mv.train()
+        return mv
+    refv = fresh_v()
+    want_loss_v = refv.fused_epoch(U, P, N, B).cpu().numpy()
+    want_v = {k: v.detach().cpu().numpy().copy() for k, v in refv.state_dict().items()}
+    for mode in ("rows", "dense"):
+        mv = fresh_v()
+        dpv = pkg.parallel.DataParallelBPR(mv, w.config, reduce=mode)
+        got_loss = dpv.train_epoch(U, P, N, B).cpu().numpy()
+        ok = ok and np.array_equal(got_loss, want_loss_v)
+        for k, v in mv.state_dict().items():
+            ok = ok and np.array_equal(v.detach().cpu().numpy().view(np.uint32), want_v[k].view(np.uint32))
+        mv.check_device_errors()
+    ok = ok and len(want_v) > 2          # (the gate's MLP parameters are in the state_dict)
     t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         open(os.path.join(work, "ok.txt"), "w").write(str(int(t.item())))
