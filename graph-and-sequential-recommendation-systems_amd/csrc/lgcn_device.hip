@@ -2713,7 +2713,6 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     int rc = check_batch(x, users, pos, neg, B_global);
     if (rc) return rc;
     if (x->variant) { lgcn_set_error("lgcn_rs_phase: the popularity gate / item-item smoothing run on one GPU only"); return 3; }
-    if (x->c.act_dtype == LGCN_FP8) { lgcn_set_error("lgcn_rs_phase: row-sharded propagation exchanges fp32 / bf16 rows; fp8 activation storage (rows + row scales) is not wired into the exchange"); return 3; }
     const lgcn_train_config &c = x->c;
     hipStream_t st = (hipStream_t)stream;
     if (world < 1 || rank < 0 || rank >= world) { lgcn_set_error("lgcn_rs_phase: bad world/rank"); return 3; }
@@ -2723,9 +2722,14 @@ extern "C" int lgcn_rs_phase(lgcn_ctx *x, int32_t phase, int32_t k, const int32_
     case LGCN_RS_FWD: {                               // X_k[owned] = (A X_{k-1})[owned], k = 1..K-1
         if (k < 1 || k > x->fwd_layers) { lgcn_set_error("lgcn_rs_phase: forward layer out of range"); return 3; }
         SpmmArgs a = base_spmm(x);
-        const bool shadow = k == 1 && x->e0b != nullptr;        // bf16 activation storage: layer 1 gathers bf16(E0), converted after every exchange
-        if (shadow) { launch_to_bf16(c.E0, x->e0b, x->N * c.d, st); x->e0b_fresh = false; }
-        a.X = k == 1 ? (shadow ? (const void *)x->e0b : (const void *)c.E0) : x->act[k - 1]; a.Y = x->act[k];
+        // bf16 / fp8 activation storage: layer 1 gathers bf16(E0) / fp8(E0), converted after every exchange of the owners' Adam rows
+        const bool shadow = k == 1 && (x->e0b != nullptr || x->e0q != nullptr);
+        if (shadow) {
+            if (x->e0b) launch_to_bf16(c.E0, x->e0b, x->N * c.d, st);
+            else if ((rc = launch_to_fp8(c.E0, x->e0q, x->N, c.d, st))) return rc;
+            x->e0b_fresh = false;
+        }
+        a.X = k == 1 ? (shadow ? (x->e0b ? (const void *)x->e0b : (const void *)x->e0q) : (const void *)c.E0) : x->act[k - 1]; a.Y = x->act[k];
         rc = launch_spmm<0>(a, c.d, k == 1 && !shadow ? LGCN_F32 : c.act_dtype, c.act_dtype, st);
         break;
     }
@@ -2774,9 +2778,11 @@ extern "C" int lgcn_rs_buffer(const lgcn_ctx *x, int32_t phase, int32_t k, void 
 }
 
 // every owner broadcasts its two row ranges (users, items) of `buf` in place; one RCCL group
-static int rs_exchange(const RcclApi *api, lgcn_dp *dp, void *buf, int dtype, int d, const int64_t *ranges, hipStream_t st) {
-    const size_t es = dtype == LGCN_BF16 ? 2 : 4;
-    const ncclDataType_t nt = dtype == LGCN_BF16 ? ncclBfloat16 : ncclFloat32;
+// (an fp8 table: the rows are d bytes each and the owners' row scales, fp32 behind the rows, travel with them)
+static int rs_exchange(const RcclApi *api, lgcn_dp *dp, void *buf, int dtype, int d, int64_t n_rows, const int64_t *ranges, hipStream_t st) {
+    const size_t es = dtype == LGCN_BF16 ? 2 : dtype == LGCN_FP8 ? 1 : 4;
+    const ncclDataType_t nt = dtype == LGCN_BF16 ? ncclBfloat16 : dtype == LGCN_FP8 ? ncclUint8 : ncclFloat32;
+    float *scales = dtype == LGCN_FP8 ? (float *)((char *)buf + (size_t)n_rows * d) : nullptr;
     ncclResult_t r = api->GroupStart();
     for (int q = 0; q < dp->world && r == ncclSuccess; q++)
         for (int part = 0; part < 2 && r == ncclSuccess; part++) {
@@ -2784,6 +2790,7 @@ static int rs_exchange(const RcclApi *api, lgcn_dp *dp, void *buf, int dtype, in
             if (hi <= lo) continue;
             char *p = (char *)buf + (size_t)lo * d * es;
             r = api->Broadcast(p, p, (size_t)(hi - lo) * d, nt, q, dp->comm, st);
+            if (scales && r == ncclSuccess) r = api->Broadcast(scales + lo, scales + lo, (size_t)(hi - lo), ncclFloat32, q, dp->comm, st);
         }
     if (r == ncclSuccess) r = api->GroupEnd(); else (void)api->GroupEnd();
     if (r != ncclSuccess) { lgcn_set_error("RCCL broadcast of owned rows failed"); return 11; }
@@ -2827,7 +2834,7 @@ static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, c
             for (int k = 1; k <= x->fwd_layers; k++) {
                 if ((rc = lgcn_rs_phase(x, LGCN_RS_FWD, k, u, p, n, b, world, rank, nullptr, nullptr, stream))) return rc;
                 if ((rc = lgcn_rs_buffer(x, LGCN_RS_FWD, k, &buf, &dt))) return rc;
-                if ((rc = rs_exchange(api, dp, buf, dt, d, row_ranges, st))) return rc;
+                if ((rc = rs_exchange(api, dp, buf, dt, d, x->N, row_ranges, st))) return rc;
             }
             if ((rc = lgcn_rs_phase(x, LGCN_RS_BPR, 0, u, p, n, b, world, rank, nullptr, nullptr, stream))) return rc;
             const int64_t S = (b + world - 1) / world, blk = 3 * S * d + 2 * S;
@@ -2837,7 +2844,7 @@ static int train_epoch_dp_impl(lgcn_ctx *x, lgcn_dp *dp, const int32_t *users, c
             for (int k = K; k >= 1; k--) {
                 if ((rc = lgcn_rs_phase(x, LGCN_RS_BWD, k, u, p, n, b, world, rank, gathered, nullptr, stream))) return rc;
                 if ((rc = lgcn_rs_buffer(x, LGCN_RS_BWD, k, &buf, &dt))) return rc;
-                if ((rc = rs_exchange(api, dp, buf, dt, d, row_ranges, st))) return rc;
+                if ((rc = rs_exchange(api, dp, buf, dt, d, x->N, row_ranges, st))) return rc;
             }
             if ((rc = lgcn_rs_phase(x, LGCN_RS_FINISH, 0, u, p, n, b, world, rank, gathered, loss_out + 3 * i, stream))) return rc;
         } else if (reduce == LGCN_DP_ROWS) {

@@ -401,7 +401,9 @@ int lgcn_train_epoch_dp(lgcn_ctx *ctx, lgcn_dp *dp, const int32_t *users, const 
  *                                                                          -> exchange lgcn_rs_buffer(BWD,k)
  *   FINISH           zero the batch rows of G64 and their flags, reduce the loss
  * Every row is computed by the same code in the same order wherever it runs, so the result is
- * bitwise identical to lgcn_train_step.  Adam state (m, v) of a row lives on its owner only.   */
+ * bitwise identical to lgcn_train_step.  Adam state (m, v) of a row lives on its owner only.
+ * An exchanged buffer of dtype LGCN_FP8 is an fp8 table (lgcn_table_bytes): a caller running the
+ * phases itself moves the owners' rows (d bytes each) AND their row scales (fp32, behind the rows).   */
 enum { LGCN_RS_FWD = 0, LGCN_RS_BPR = 1, LGCN_RS_SCATTER = 2, LGCN_RS_BWD = 3, LGCN_RS_FINISH = 4 };
 int lgcn_rs_phase(lgcn_ctx *ctx, int32_t phase, int32_t k, const int32_t *users, const int32_t *pos,
                   const int32_t *neg, int32_t B_global, int32_t world, int32_t rank,

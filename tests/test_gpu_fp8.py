@@ -171,12 +171,15 @@ def test_fp8_activation_mode_propagation_and_step(pkg, oracle, tiny, lastfm, tmp
     assert l2 == l_got and torch.equal(m2._table, m._table)
 
 
-@pytest.mark.parametrize("mode", ["rows", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "dense", "row_sharded"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_fp8_dp_epoch_loopback_bitwise(pkg, tiny, tmp_path, world, mode):
     """fp8 activation storage under data parallelism (the C loop through the loopback communicator): replicas quantise the same
     numbers the same way, the gradient exchange is fixed point -- every rank ends bit for bit where the single-GPU epoch ends.
-    Row-sharded propagation refuses fp8 (its exchange moves fp32 / bf16 rows)."""
+    Row-sharded propagation: every owner quantises its own rows (a row's scale depends on that row alone) and broadcasts the row
+    bytes AND the row scales; layer 1 gathers fp8(E0), requantised after every exchange of the owners' Adam rows.
+    Then: one rank fails before its first collective (its context was made for a smaller batch) while the other is already waiting
+    in the all-gather -- the failing rank's exit must release it (loopback abort) instead of leaving it there."""
     import threading
     g = tiny
     rng = np.random.Generator(np.random.PCG64(29 * world + len(mode)))
@@ -190,10 +193,13 @@ def test_fp8_dp_epoch_loopback_bitwise(pkg, tiny, tmp_path, world, mode):
     L, lib = pkg._lib, pkg._lib.load()
     models = [_make_model(pkg, g, tmp_path, act_dtype="fp8", B=B)[1] for _ in range(world)]
     par = pkg.parallel
-    states = [mm._state(max_batch=B, need_ctx=True, dp_world=world) for mm in models]
+    ranges = par.row_ranges(models[0]._adj.indptr, models[0].n_users, world) if mode == "row_sharded" else None
+    rr = np.ascontiguousarray(ranges, np.int64) if ranges is not None else None
+    states = [mm._state(max_batch=B, need_ctx=True, dp_world=world,
+                        row_subset=par.owned_rows(ranges, r) if ranges is not None else None) for r, mm in enumerate(models)]
     comms = (C.c_void_p * world)()
     L.check(lib.lgcn_dp_init_loopback(world, comms), "loopback")
-    code = {"rows": 0, "dense": 1}[mode]
+    code = {"rows": 0, "dense": 1, "row_sharded": 2}[mode]
     steps = (T + B - 1) // B
     streams = [torch.cuda.Stream() for _ in range(world)]
     gathered = [torch.empty(world * par.block_numel(B, world, g.d), device=DEV) for _ in range(world)]
@@ -202,7 +208,7 @@ def test_fp8_dp_epoch_loopback_bitwise(pkg, tiny, tmp_path, world, mode):
     rcs, errs = [None] * world, [None] * world
 
     def rank_main(r):
-        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, code, None,
+        rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, code, L.npp(rr) if rr is not None else None,
                                          L.tp(gathered[r]), L.tp(losses[r]), C.c_void_p(streams[r].cuda_stream))
         if rcs[r]:
             errs[r] = lib.lgcn_last_error()
@@ -218,19 +224,21 @@ def test_fp8_dp_epoch_loopback_bitwise(pkg, tiny, tmp_path, world, mode):
         assert np.array_equal(losses[r].cpu().numpy(), want_loss), (mode, world, r)
         assert np.array_equal(mm._table.cpu().numpy().view(np.uint32), want), (mode, world, r)
         mm.check_device_errors()
-    if mode == "rows" and world == 2:          # row-sharded propagation: refused, and the refusal releases the other rank (loopback abort)
-        ranges = par.row_ranges(models[0]._adj.indptr, models[0].n_users, world)
-        rr = np.ascontiguousarray(ranges, np.int64)
+    if mode == "rows" and world == 2:          # rank 1 leaves before its first collective; rank 0 is released, not left waiting
+        small = _make_model(pkg, g, tmp_path, act_dtype="fp8", B=B // 2)[1]
+        st_small = small._state(max_batch=B // 2, need_ctx=True, dp_world=world)
+        ctxs = [states[0]['ctx'], st_small['ctx']]
         rcs = [None] * world
 
-        def rs_main(r):
-            rcs[r] = lib.lgcn_train_epoch_dp(states[r]['ctx'], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, 2, L.npp(rr),
+        def ab_main(r):
+            rcs[r] = lib.lgcn_train_epoch_dp(ctxs[r], comms[r], L.tp(U), L.tp(P), L.tp(Nn), T, B, 0, None,
                                              L.tp(gathered[r]), L.tp(losses[r]), C.c_void_p(streams[r].cuda_stream))
-        threads = [threading.Thread(target=rs_main, args=(r,)) for r in range(world)]
+        threads = [threading.Thread(target=ab_main, args=(r,)) for r in range(world)]
         for t in threads:
             t.start()
         for t in threads:
             t.join(timeout=60)
-        assert not any(t.is_alive() for t in threads) and all(rc == 3 for rc in rcs), rcs
+        torch.cuda.synchronize()
+        assert not any(t.is_alive() for t in threads) and rcs[1] == 3 and rcs[0] not in (0, None), rcs
     for r in range(world):
         lib.lgcn_dp_destroy(comms[r])
