@@ -25,7 +25,7 @@ def test_bench_self_launches_two_ranks():
     assert len(lines) == 1, p.stdout
     j = json.loads(lines[0])
     assert j["dry_run"] and j["n_gpus"] == 2 and j["max_rank_plus_1"] == 2.0
-    assert j["steps"] == 7 and j["warmup"] == 2 and j["workload"] == "amazon-book-shaped"
+    assert j["steps"] == 7 and j["warmup"] == 2 and j["workload"] == "amazon-book-shaped" and j["act_dtype"] == "fp32"
     # default = strong scaling: the reference's ONE global batch of 2048 is sharded
     assert j["scaling"] == "strong" and j["global_batch"] == 2048
     # the ranks the collectives really span (an all-reduce of 1 per rank), not WORLD_SIZE; the 400-step steady-state region
@@ -44,6 +44,10 @@ def test_bench_single_rank_and_mismatch():
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["workload"] == "gowalla" and j["steps"] == 400 and j["warmup"] == 20
+    # BASELINE configs[1] ("Gowalla 3-layer dim=64 bf16") names the storage type: the default there, fp32 on the other workloads
+    assert j["act_dtype"] == "bf16"
+    j32 = json.loads([l for l in _run(["--act_dtype", "fp32"]).stdout.splitlines() if l.startswith("{")][0])
+    assert j32["act_dtype"] == "fp32"
     # N = 1: "scaling" is the configured mode (config.scaling_mode says the same), one rank observed, and the line carries
     # the end-to-end epoch rate and the 10-epoch quality object next to roofline / cpu_baseline
     assert j["scaling"] == "strong" and j["rccl_ranks_observed"] == 1
