@@ -354,6 +354,7 @@ def main():
     # same workload with the other activation storage type -- so that the headline's K steps run on a GPU that is
     # already at its working clocks (a 20-step region right after set-up measured 4-5 % under steady state).
     reps = a.spmm_reps if a.workload != "synthetic-10m" else 5
+    t_spmm = spmm_kernel_time(reps)      # ~50 ms of back-to-back launches: also what brings the GPU to its working clocks for the legs below
     secondary = None
     if rank == 0 and not use_dp and not a.no_secondary and a.workload != "synthetic-10m":
         other = "bf16" if a.act_dtype != "bf16" else "fp32"
@@ -368,7 +369,7 @@ def main():
         torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
         secondary = (other, a.steps / dt2, spmm_kernel_time(max(200, reps // 4), ACT[other][0]))
         del model2
-    t_spmm = spmm_kernel_time(reps)      # ~3 ms of back-to-back launches, directly ahead of the warm-up steps
+    spmm_kernel_time(min(200, reps))     # (a short burst directly ahead of the warm-up steps)
 
     run(0, a.warmup)
     progress(f"timed region ({a.steps} steps)")
