@@ -7,7 +7,7 @@ path, and nothing of the reference's source text is written to the repo: the
 outputs are data only (inputs + expected outputs as .npz / .json / .txt
 interaction lists).
 
-Usage:  python tests/golden/make_golden.py [tiny] [lastfm] [gowalla] [gowalla_long] [tiny_gate] [tiny_i2i] [tiny_gate_i2i]
+Usage:  python tests/golden/make_golden.py [tiny] [lastfm] [gowalla] [gowalla_long] [tiny_gate] [tiny_i2i] [tiny_gate_i2i] [tiny_gate_i2i_k1|_k2|_k4]
 
 What the reference pieces are (all paths relative to
 /root/reference/LightGCN_work/code):
@@ -427,13 +427,15 @@ def make_tiny_i2i(train_dir, out_npz):
     return C
 
 
-def gen_variant(tag, gate, i2i, out_dir):
+def gen_variant(tag, gate, i2i, out_dir, K=3):
     """The fork's optional branches on the tiny dataset: popularity gate (model.py:66-96,139-157,176-181)
-    and item-item smoothing (model.py:99-109,228-229), through the reference's own model / BPRLoss."""
+    and item-item smoothing (model.py:99-109,228-229), through the reference's own model / BPRLoss.
+    K: propagation depth (targets tiny_gate_i2i_k1 / _k2 / _k4: the depths at which the product's fused step takes other
+    code paths -- one row bitmap and k_finish at K = 1, alternating bitmaps at 2 / 4 -- pinned by the reference too)."""
     os.makedirs(out_dir, exist_ok=True)
     work = tempfile.mkdtemp(prefix="golden_" + tag)
     make_tiny(work)
-    K, d, B = 3, 64, 64
+    d, B = 64, 64
     import torch
     world, dataloader, model, utils, Procedure = import_reference("tiny")
     world.config["lightGCN_n_layers"], world.config["latent_dim_rec"], world.config["bpr_batch_size"] = K, d, B
@@ -441,7 +443,8 @@ def gen_variant(tag, gate, i2i, out_dir):
     alpha = 0.3
     if i2i:
         i2i_path = os.path.join(out_dir, "i2i_tiny.npz")
-        make_tiny_i2i(work, i2i_path)
+        if not os.path.exists(i2i_path):
+            make_tiny_i2i(work, i2i_path)
         world.config["use_item_item"], world.config["i2i_path"], world.config["i2i_alpha"] = True, i2i_path, alpha
     dataset = dataloader.Loader(world.config, path=work)
     utils.sample_ext = False
@@ -517,6 +520,8 @@ if __name__ == "__main__":
         gen_gowalla(os.path.join(HERE, "gowalla"), 1, "short")
     elif w in ("tiny_gate", "tiny_i2i", "tiny_gate_i2i"):
         gen_variant(w[5:], "gate" in w, "i2i" in w, os.path.join(HERE, "tiny"))
+    elif w in ("tiny_gate_i2i_k1", "tiny_gate_i2i_k2", "tiny_gate_i2i_k4"):
+        gen_variant(w[5:], True, True, os.path.join(HERE, "tiny"), K=int(w[-1]))
     elif w == "gowalla_long":
         gen_gowalla(os.path.join(HERE, "gowalla"), 10, "long")
     else:

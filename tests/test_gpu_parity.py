@@ -912,11 +912,12 @@ def test_triplet_kernel_unit_boundaries(pkg, oracle, tmp_path, d, K, act, hub):
 
 
 @pytest.mark.parametrize("path", ["fused", "autograd"])
-@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i"])
+@pytest.mark.parametrize("tag", ["gate", "i2i", "gate_i2i", "gate_i2i_k1", "gate_i2i_k2", "gate_i2i_k4"])
 def test_optional_branches_vs_reference_golden(pkg, tiny, tmp_path, tag, path):
     """the fork's popularity gate (model.py:66-96,139-157,176-181) and item-item smoothing
     (model.py:99-109,228-229) against fixtures captured from the reference itself on the tiny dataset
-    (tests/golden/make_golden.py tiny_gate / tiny_i2i / tiny_gate_i2i): initial parameters bit for bit (same
+    (tests/golden/make_golden.py tiny_gate / tiny_i2i / tiny_gate_i2i at K = 3, and tiny_gate_i2i_k1 / _k2 / _k4: both branches at the other
+    depths -- K = 1 keeps one row bitmap and ends in k_finish, 2 / 4 alternate two): initial parameters bit for bit (same
     modules built in the same order from seed 2020), computer(), ratings, Test metrics, bpr_loss and the
     gradient of EVERY parameter, then three stageOne steps and the metrics after.
     path = "fused": the branches run INSIDE the fused HIP step (k_mean_layers, the item-item SpMMs, k_triplet_gate,
