@@ -1118,12 +1118,18 @@ __device__ __forceinline__ void triplet_finish(const BprArgs &a, int b, int l, c
 #define TRIPLET_WAVES 4        /* waves per k_triplet workgroup: 4 = three gathering waves + one that reads the lower layers' rows; 3 = every wave
                                   reads the lower-layer rows of its own slot before it gathers (more workgroups resident per CU) */
 #endif
+#ifndef TRIPLET_WAVES_BF16
+#define TRIPLET_WAVES_BF16 3   /* bf16 tables: three (measured again in run 27: Gowalla bf16 8 312 / 8 260 -> 8 398 / 8 417 steps/s; fp32 tables
+                                  6 572 / 6 523 vs 6 518 / 6 560: no difference, four stays) */
+#endif
+// waves per k_triplet workgroup for a table type
+template <typename TI> struct TripletGeo { static constexpr int NW = sizeof(TI) == 2 ? TRIPLET_WAVES_BF16 : TRIPLET_WAVES; };
 #ifndef ROWS_UNIT_TILES
 #define ROWS_UNIT_TILES 2      /* 64-entry tiles per unit of a slot row */
 #endif
-// units u_first, u_first + 4, ... of the row [start, start + n): one wave's share of a slot row.  The next
+// units u_first, u_first + NW, ... of the row [start, start + n): one wave's share of a slot row.  The next
 // tile's (col,val) pairs are in flight while this tile gathers, across the unit boundaries too.
-template <int D, typename TG, bool BIG, typename ES>
+template <int D, typename TG, bool BIG, int NW, typename ES>
 __device__ __forceinline__ typename Geo<D, TG, false>::Acc
 units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &src, int lane, int2 *stage) {
     typedef Geo<D, TG, false> G;
@@ -1139,7 +1145,7 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
         const int cnt = tile_stage<false>(cv.x, __int_as_float(cv.y), min(64, n - t * 64), src, lane, stage);
         __builtin_amdgcn_wave_barrier();
         int tn = t + 1;
-        if (tn % UT == 0) tn += (TRIPLET_WAVES - 1) * UT;
+        if (tn % UT == 0) tn += (NW - 1) * UT;
         const bool more = tn < ntiles;
         cv = make_int2(0, 0);
         if (more && tn * 64 + lane < n) cv = es.at(start + tn * 64 + lane);
@@ -1153,8 +1159,8 @@ units_gather(const ES &es, int64_t start, int n, int u_first, const GatherSrc &s
 
 // TG: type of the table the last layer gathers from (X_{K-1}; E0 itself when K == 1)
 template <int D, typename TG, typename TI, bool BIG>
-__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[TRIPLET_WAVES][D], float (*base)[D], float (*ego)[D]) {
-    constexpr int NW = TRIPLET_WAVES;
+__device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, int2 *stage, float (*part)[TripletGeo<TI>::NW][D], float (*base)[D], float (*ego)[D]) {
+    constexpr int NW = TripletGeo<TI>::NW;
     typedef Geo<D, TG, false> G;
     constexpr int C = G::CPL, LPR = G::LPR, UN = 64 * ROWS_UNIT_TILES;
     constexpr int LPT = D < 64 ? D : 64, CPT = D / LPT;      // lane = column (mod 64) layout of the finishing steps
@@ -1192,7 +1198,7 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
         const int stc = c == 0 ? st0 : (c == 1 ? st1 : st2), nc = c == 0 ? n0 : (c == 1 ? n1 : n2);
         const int u0 = NW == 4 ? ((w - c + 4) & 3) : ((w - c + 3) % 3), units = (a.hub_nnz && nc > a.hub_nnz) ? 0 : (nc + UN - 1) / UN;      // a hub row: computed by the hub plan
         if (u0 < units) {
-            const typename G::Acc x = units_gather<D, TG, BIG>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
+            const typename G::Acc x = units_gather<D, TG, BIG, NW>(CsrSrc{a.indices, a.vals}, stc, nc, u0, src, lane, stage);
             if (lane < LPR) {
                 if constexpr (sizeof(TG) == 1) {       // an fp8 gather: the lane's values are the chunks j*LPR + lane (see fp8_t)
 #pragma unroll
@@ -1235,13 +1241,14 @@ __device__ __forceinline__ void triplet_body(const BprArgs &a, const void *Xg, i
 }
 
 template <int D, typename TI, bool BIG>
-__global__ void __launch_bounds__(64 * TRIPLET_WAVES, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
-    __shared__ int2 stage_lds[TRIPLET_WAVES][TILE_ST];
-    __shared__ __attribute__((aligned(32))) float part_lds[3][TRIPLET_WAVES][D];
+__global__ void __launch_bounds__(64 * TripletGeo<TI>::NW, sizeof(TI) == 4 ? TRIPLET_MIN_WAVES_F32 : TRIPLET_MIN_WAVES) k_triplet(BprArgs a) {
+    constexpr int NW = TripletGeo<TI>::NW;
+    __shared__ int2 stage_lds[NW][TILE_ST];
+    __shared__ __attribute__((aligned(32))) float part_lds[3][NW][D];
     __shared__ float base_lds[3][D];
     __shared__ float ego_lds[3][D];          // reg_ego: the slots' rows of the table itself
     // last step's row bitmap is dead: zero it here with plain stores (the two bitmaps alternate per step)
-    for (int64_t i = (int64_t)blockIdx.x * (64 * TRIPLET_WAVES) + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * (64 * TRIPLET_WAVES))
+    for (int64_t i = (int64_t)blockIdx.x * (64 * NW) + threadIdx.x; i < a.bitmap_words; i += (int64_t)gridDim.x * (64 * NW))
         a.stale_bitmap[i] = 0u;
     int2 *stage = stage_lds[threadIdx.x >> 6];
     if (a.K == 1) triplet_body<D, float, TI, BIG>(a, a.X0, stage, part_lds, base_lds, ego_lds);
@@ -2121,7 +2128,6 @@ struct lgcn_ctx {
     uint32_t *item_bitmap;        // [ceil(m_items/32)] items named by the batch (item-item backward), library-owned
     long long *gate_partials;     // [n_wg, P] parameter-gradient partial sums, fixed point (library-owned)
     long long *gate_total;        // [P] this rank's sum of them, all-reduced by the dense data-parallel form (behind gate_partials)
-    bool gate_total_live;         // the next backward takes the MLP gradient from gate_total
     int32_t gate_P, gate_wgs;
     int32_t *cnt;                 // reg_ego: [N] slots of the running step naming each row (library-owned, zero between steps)
     float *colsum;                // [3 * max_batch] partial scores / reg terms of a column-sharded step (library-owned)
@@ -2168,7 +2174,7 @@ extern "C" int lgcn_ctx_create(const lgcn_train_config *cfg, lgcn_ctx **out) {
     // rows that are never flagged are never read; zero-filled so that the zero-weight padding reads of row 0 stay finite
     x->g32 = nullptr; x->e0b = nullptr; x->e0q = nullptr; x->e0b_fresh = false; x->in_loop = false; x->dp_local = false; x->dp_rank = -1;
     x->hub_graph = nullptr; x->hub_nnz = 0; x->hub_rows = 0;
-    x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_total = nullptr; x->gate_total_live = false; x->gate_P = 0; x->gate_wgs = 0;
+    x->variant = gate || smooth; x->tvar = nullptr; x->item_bitmap = nullptr; x->gate_partials = nullptr; x->gate_total = nullptr; x->gate_P = 0; x->gate_wgs = 0;
     const size_t gbytes = (size_t)x->N * c.d * sizeof(float);
     bool ok = hipMalloc((void **)&x->g32, gbytes) == hipSuccess && hipMemset(x->g32, 0, gbytes) == hipSuccess;
     if (ok) ok = hipMalloc((void **)&x->colsum, sizeof(float) * 3 * (size_t)c.max_batch) == hipSuccess;
@@ -2328,8 +2334,8 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
                 if (c.dense_last) {
                     const int tpb = 256 / 64;
                     hipLaunchKernelGGL((k_triplet_dense<D, fp8_t>), dim3((unsigned)((B_local + tpb - 1) / tpb)), dim3(256), 0, st, a);
-                } else if (big_table(x->N, D)) hipLaunchKernelGGL((k_triplet<D, fp8_t, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
-                else hipLaunchKernelGGL((k_triplet<D, fp8_t, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+                } else if (big_table(x->N, D)) hipLaunchKernelGGL((k_triplet<D, fp8_t, true>), dim3(B_local), dim3(64 * TripletGeo<fp8_t>::NW), 0, st, a);
+                else hipLaunchKernelGGL((k_triplet<D, fp8_t, false>), dim3(B_local), dim3(64 * TripletGeo<fp8_t>::NW), 0, st, a);
             }
         } else if (c.dense_last) {
             const int tpb = 256 / (D < 64 ? D : 64);
@@ -2337,10 +2343,10 @@ static int run_bpr(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const 
             if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet_dense<D, float>), dim3(gd), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_triplet_dense<D, bf16_t>), dim3(gd), dim3(256), 0, st, a);
         } else if (big_table(x->N, D)) {
-            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
-            else hipLaunchKernelGGL((k_triplet<D, bf16_t, true>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
-        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
-        else hipLaunchKernelGGL((k_triplet<D, bf16_t, false>), dim3(B_local), dim3(64 * TRIPLET_WAVES), 0, st, a);
+            if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, true>), dim3(B_local), dim3(64 * TripletGeo<float>::NW), 0, st, a);
+            else hipLaunchKernelGGL((k_triplet<D, bf16_t, true>), dim3(B_local), dim3(64 * TripletGeo<bf16_t>::NW), 0, st, a);
+        } else if (c.act_dtype == LGCN_F32) hipLaunchKernelGGL((k_triplet<D, float, false>), dim3(B_local), dim3(64 * TripletGeo<float>::NW), 0, st, a);
+        else hipLaunchKernelGGL((k_triplet<D, bf16_t, false>), dim3(B_local), dim3(64 * TripletGeo<bf16_t>::NW), 0, st, a);
     });
     return 0;
 }
@@ -2517,8 +2523,9 @@ static int backward_layer(lgcn_ctx *x, int k, const int32_t *users, const int32_
 }
 
 // [DP scatter] + backward chain + Adam + finish
+// gate_reduced: the MLP gradient of the global batch is the all-reduced gate_total (dense data-parallel form)
 static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, const int32_t *neg, int32_t B,
-                        const float *gathered, int32_t shard, int32_t world, float *loss_out, hipStream_t st) {
+                        const float *gathered, int32_t shard, int32_t world, float *loss_out, hipStream_t st, bool gate_reduced = false) {
     const lgcn_train_config &c = x->c;
     { int rc0 = graph_acquire(c.graph, st); if (rc0) return rc0; }
     SlotArgs s = slot_args(x, users, pos, neg, B, gathered, shard, world, loss_out);
@@ -2537,8 +2544,8 @@ static int run_backward(lgcn_ctx *x, const int32_t *users, const int32_t *pos, c
         GateAdamArgs ga{};
         if (gathered) {      // data parallel: the ranks' totals sit in the tails of their exchange blocks
             ga.src = (const long long *)(gathered + dp_block_tail(x, shard)); ga.n_src = world; ga.stride = dp_block_floats(x, shard) / 2;
-        } else if (x->gate_total_live) {      // dense form: the all-reduced total
-            ga.src = x->gate_total; ga.n_src = 1; ga.stride = x->gate_P; x->gate_total_live = false;
+        } else if (gate_reduced) {             // dense form: the all-reduced total
+            ga.src = x->gate_total; ga.n_src = 1; ga.stride = x->gate_P;
         } else { ga.src = x->gate_partials; ga.n_src = (B + GATE_TPB - 1) / GATE_TPB; ga.stride = x->gate_P; }
         ga.P = x->gate_P;
         ga.params = c.gate_params; ga.m = c.gate_adam_m; ga.v = c.gate_adam_v; ga.grad_out = c.gate_grad;
@@ -2639,7 +2646,6 @@ extern "C" int lgcn_train_step_dp_dense_part1(lgcn_ctx *x, const int32_t *users,
                 hipLaunchKernelGGL(k_gate_rank_total, dim3((unsigned)((x->gate_P + 255) / 256)), dim3(256), 0, st,
                                    (const long long *)x->gate_partials, (int32_t)((B_local + GATE_TPB - 1) / GATE_TPB), x->gate_P, x->gate_total);
             else HIP_OK(hipMemsetAsync(x->gate_total, 0, sizeof(long long) * (size_t)x->gate_P, st));
-            x->gate_total_live = true;
         }
     } else if ((rc = run_bpr(x, users, pos, neg, B_global, b_off, B_local, shard, true, false, st, false))) return rc;
     SlotArgs s{};
@@ -2664,7 +2670,8 @@ extern "C" int lgcn_train_step_dp_part2(lgcn_ctx *x, const int32_t *users, const
     if (rc) return rc;
     if (!loss_out || world < 1) { lgcn_set_error("dp step part 2: invalid argument"); return 3; }
     const int32_t shard = (B_global + world - 1) / world;
-    if ((rc = run_backward(x, users, pos, neg, B_global, gathered, shard, world, loss_out, (hipStream_t)stream))) return rc;
+    // gathered == NULL is the dense form: G64, the terms and (popularity gate) gate_total hold the reduced sums of the global batch
+    if ((rc = run_backward(x, users, pos, neg, B_global, gathered, shard, world, loss_out, (hipStream_t)stream, gathered == nullptr))) return rc;
     HIP_OK(hipGetLastError());
     return 0;
 }
