@@ -634,6 +634,9 @@ template <int NPW> struct PackGeo { static constexpr int PACKS = NPW >= SPMM_WAV
 #ifndef SPMM_GPR_BF16
 #define SPMM_GPR_BF16 2
 #endif
+#ifndef SPMM_SCALAR_ROWINFO
+#define SPMM_SCALAR_ROWINFO 1  /* a pack's row descriptors and bitmap words through the scalar cache instead of vector loads + readlane */
+#endif
 #ifndef SPMM_ADAM_SPLIT
 #define SPMM_ADAM_SPLIT 1     /* bf16 tables: the two lane groups of a row share its Adam epilogue (see k_spmm) */
 #endif
@@ -768,6 +771,31 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
 #pragma unroll 1
     for (int pk = 0; pk < PACKS; pk++) {
         const int64_t pos0 = (int64_t)a.sp.rows[x] + (int64_t)t * RPB + (wid * PACKS + pk) * RPK;
+        int off[RPK + 1];
+        off[0] = 0;
+#if SPMM_SCALAR_ROWINFO
+        // The pack's row descriptors (row id, first entry, count) are the same for every lane and constant during the launch:
+        // SCALAR loads (constant address space -> s_load_dwordx4), no vector-memory instruction and no readlane for them -- these
+        // kernels are bound by the vector-memory instructions a CU retires (experiments.txt run 29-31).  The rows' bitmap words
+        // likewise (k_spmm only reads the bitmap).
+        typedef int i32x4_ __attribute__((ext_vector_type(4)));          // (a plain vector type: HIP's int4 is a class on the host pass)
+        typedef const __attribute__((address_space(4))) i32x4_ *kint4p;
+        typedef const __attribute__((address_space(4))) uint32_t *ku32p;
+        const kint4p rip = (kint4p)(a.rowinfo + pos0);
+        int row_s[RPK];
+        int64_t base = 0;
+#pragma unroll
+        for (int r = 0; r < RPK; r++) {
+            const i32x4_ ri = rip[r];
+            row_s[r] = ri.x; off[r + 1] = off[r] + ri.z;
+            if (r == 0) base = ri.y;
+        }
+        if (row_s[0] < 0) break;                                   // padding is at the end of a slice
+        uint32_t fw_s[RPK];
+#pragma unroll
+        for (int r = 0; r < RPK; r++) fw_s[r] = ((MODE & M_ADDG) && row_s[r] >= 0) ? ((ku32p)a.bitmap)[row_s[r] >> 5] : 0u;
+        const int tot = off[RPK];
+#else
         // lane r < RPK fetches (row id, first entry, count) of row r with ONE 16-byte load from the plan
         int my_row = -1, my_s = 0, my_n = 0;
         if (lane < RPK) {
@@ -777,14 +805,13 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
         uint32_t my_fw = 0u;           // bitmap word of this lane's row, in flight under the stream loads
         if ((MODE & M_ADDG) && my_row >= 0) my_fw = a.bitmap[my_row >> 5];
         if (__builtin_amdgcn_readlane(my_row, 0) < 0) break;       // padding is at the end of a slice
-        // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
-        // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
-        int off[RPK + 1];
-        off[0] = 0;
 #pragma unroll
         for (int r = 0; r < RPK; r++) off[r + 1] = off[r] + __builtin_amdgcn_readlane(my_n, r);
         const int tot = off[RPK];
         const int64_t base = __builtin_amdgcn_readlane(my_s, 0);
+#endif
+        // the pack's rows are contiguous in the stream: entry e of the pack belongs to the row r with
+        // off[r] <= e < off[r+1]; whole 512-byte loads, all issued before the first is staged
         int2 cvr[RPK];
 #pragma unroll
         for (int it = 0; it < RPK; it++) {
@@ -863,7 +890,15 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
         Acc acc = zerov<C>();
         // batch depth follows the pack's longest row (8 / 4 / 2 / 1 gathers per lane): a padded gather costs
         // the address path as much as a useful one
+#if SPMM_SCALAR_ROWINFO
+        int mrow = row_s[0];
+        uint32_t mfw = fw_s[0];
+#pragma unroll
+        for (int r = 1; r < RPK; r++) { mrow = myr == r ? row_s[r] : mrow; mfw = myr == r ? fw_s[r] : mfw; }
+#else
         const int mrow = __shfl(my_row, myr);
+        const uint32_t mfw = (MODE & M_ADDG) ? (uint32_t)__shfl((int)my_fw, myr) : 0u;
+#endif
         // (fp32 tables only: with a bf16 table the kernel is already at its register budget and the operands spill --
         //  measured 6940 vs 7420 steps/s; fp32: 6339 vs 6306)
         //  with the two lane groups of a bf16 row sharing the epilogue -- SPLIT below -- the operands are 12 registers, not 24)
@@ -883,7 +918,7 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
 #pragma unroll
             for (int i = 0; i < C; i++) acc[i] = sum_row_groups<LPR, GPR>(acc[i], lane);     // fixed order: bitwise reproducible
         }
-        const bool mflag = (MODE & M_ADDG) ? ((__shfl(my_fw, myr) >> (mrow & 31)) & 1u) != 0u : false;
+        const bool mflag = (MODE & M_ADDG) ? ((mfw >> (mrow & 31)) & 1u) != 0u : false;
         if constexpr (SPLIT) {
             // bf16 table, Adam: both lane groups of the row hold its sums, so BOTH run the fp32 epilogue, group `sub`
             // on the 4-column chunk 2l + sub.  One float4 per operand and lane, whole 64-byte lines per instruction
