@@ -714,12 +714,24 @@ __global__ void __launch_bounds__(64 * SPMM_WPB, sizeof(TI) == 1 ? 4 : ((MODE & 
     if (j < ncb) {
         // ---- one chunk of a long row, the whole wave on it ----
         const int c = a.sp.cblk[x] * 4 + j * SPMM_WPB + wid;
+#if SPMM_SCALAR_ROWINFO
+        // (the chunk's descriptor, its row and the row's bitmap word are wave-uniform plan data: scalar loads, as for the packs below)
+        typedef int i32x4c_ __attribute__((ext_vector_type(4)));
+        const i32x4c_ chv = ((const __attribute__((address_space(4))) i32x4c_ *)a.lp.chunks)[c];
+        const int4 ch = make_int4(chv.x, chv.y, chv.z, chv.w);
+        const int o = ch.x;
+        if (o < 0) return;
+        const int64_t row = ((const __attribute__((address_space(4))) int32_t *)a.lp.long_row)[o];
+        const int nch = ((const __attribute__((address_space(4))) int32_t *)a.lp.long_nch)[o];
+        const bool rflag = (MODE & M_ADDG) ? ((((const __attribute__((address_space(4))) uint32_t *)a.bitmap)[row >> 5] >> (row & 31)) & 1u) != 0u : false;
+#else
         const int4 ch = a.lp.chunks[c];
         const int o = ch.x;
         if (o < 0) return;
         const int64_t row = a.lp.long_row[o];
         const int nch = a.lp.long_nch[o];
         const bool rflag = (MODE & M_ADDG) ? bit_set(a.bitmap, (int)row) : false;
+#endif
         Acc acc = row_gather<D, TI, SP, BIG>(PackedSrc{a.pk}, ch.y, ch.z, src, lane, stage_lds[wid]);
         if (nch == 1) {                                   // LONG_T < nnz <= LONG_CH: one wave, no hand-off
             if (lane < LPR) spmm_epilogue<D, TO, MODE, C, IL>(a, row, lane, acc, rflag);
